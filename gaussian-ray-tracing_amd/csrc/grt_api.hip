@@ -1,0 +1,511 @@
+// grt_api.hip — C ABI of libgrt_hip.so (include/grt.h): context, scene upload, BVH build driver,
+// render entry points.  No CPU fallback: every entry point that needs the GPU fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "grt_device.h"
+#include "grt_internal.h"
+
+using namespace grt;
+
+static thread_local std::string g_create_err;
+
+#define CHK(ctx, x)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            (ctx)->err = std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"; \
+            return GRT_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// scene kernels
+// ------------------------------------------------------------------------------------------------
+
+// World AABB of the proxy icosahedron M = T * (R * diag(scale*s)) (src/GaussianTracer.cpp:304-311,
+// src/geometry/Icosahedron.h:13-37).  opacity <= alpha_min gives s = NaN/0 in the reference, i.e. an
+// unhittable instance: such particles get an inverted box and are left out of the BVH.
+__global__ void k_proxy_boxes(const float* __restrict__ pos, const float* __restrict__ scale,
+                              const float* __restrict__ quat, const float* __restrict__ s_arr, uint32_t n,
+                              float4* __restrict__ lo, float4* __restrict__ hi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = s_arr[i];
+    if (!(s > 0.0f)) {
+        lo[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        hi[i] = make_float4(-1.0f, -1.0f, -1.0f, 0.0f);
+        return;
+    }
+    const float rr = (3.0f + sqrtf(5.0f)) / (2.0f * sqrtf(3.0f));
+    const float ss = 1.0f / rr;
+    const float tt = (1.0f + sqrtf(5.0f)) / (2.0f * rr);
+    const float V[12][3] = {{-ss, tt, 0}, {ss, tt, 0}, {-ss, -tt, 0}, {ss, -tt, 0}, {0, -ss, tt}, {0, ss, tt},
+                            {0, -ss, -tt}, {0, ss, -tt}, {tt, 0, -ss}, {tt, 0, ss}, {-tt, 0, -ss}, {-tt, 0, ss}};
+    float Rg[9];
+    mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
+    const float sx = scale[i * 3] * s, sy = scale[i * 3 + 1] * s, sz = scale[i * 3 + 2] * s;
+    float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int v = 0; v < 12; v++) {
+        const float lx = sx * V[v][0], ly = sy * V[v][1], lz = sz * V[v][2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float w = (Rg[0 * 3 + r] * lx + Rg[1 * 3 + r] * ly) + Rg[2 * 3 + r] * lz + pos[i * 3 + r];
+            l[r] = fminf(l[r], w);
+            h[r] = fmaxf(h[r], w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float e = 1e-5f * (1.0f + fmaxf(fabsf(l[r]), fabsf(h[r])));
+        l[r] -= e;
+        h[r] += e;
+    }
+    lo[i] = make_float4(l[0], l[1], l[2], 0.0f);
+    hi[i] = make_float4(h[0], h[1], h[2], 0.0f);
+}
+
+// Proxy record in Morton order, 64 B = 4 x float4:
+//   (mu.x mu.y mu.z s) (A00 A01 A02 opacity) (A10 A11 A12 id-bits) (A20 A21 A22 0)
+// A = diag(1/scale) * R^T exactly as computeResponse forms it per hit (shaders/tracer.cuh:191-201).
+__global__ void k_gather_records(const float* __restrict__ pos, const float* __restrict__ scale,
+                                 const float* __restrict__ quat, const float* __restrict__ opacity,
+                                 const float* __restrict__ s_arr, const uint32_t* __restrict__ order, uint32_t m,
+                                 float4* __restrict__ rec)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t i = order[j];
+    float Rg[9];
+    mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
+    float A[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float inv = 1.0f / scale[i * 3 + r];
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[r * 3 + c] = inv * Rg[r * 3 + c];
+    }
+    rec[(size_t)j * 4 + 0] = make_float4(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], s_arr[i]);
+    rec[(size_t)j * 4 + 1] = make_float4(A[0], A[1], A[2], opacity[i]);
+    rec[(size_t)j * 4 + 2] = make_float4(A[3], A[4], A[5], __uint_as_float(i));
+    rec[(size_t)j * 4 + 3] = make_float4(A[6], A[7], A[8], 0.0f);
+}
+
+// degree-0 radiance max(0.5 + SH_C0 * sh[0], 0) (shaders/tracer.cuh:223,263), by original id
+__global__ void k_color0(const float* __restrict__ sh, uint32_t n, float4* __restrict__ color0)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* s = sh + (size_t)i * 48;
+    color0[i] = make_float4(fmaxf(0.5f + GRT_SH_C0 * s[0], 0.0f), fmaxf(0.5f + GRT_SH_C0 * s[1], 0.0f),
+                            fmaxf(0.5f + GRT_SH_C0 * s[2], 0.0f), 0.0f);
+}
+
+__global__ void k_tri_boxes(const float* __restrict__ verts, const uint32_t* __restrict__ faces, uint32_t nf,
+                            float4* __restrict__ lo, float4* __restrict__ hi)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nf) return;
+    float l[3], h[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float a = verts[faces[f * 3] * 3 + k], b = verts[faces[f * 3 + 1] * 3 + k],
+                    c = verts[faces[f * 3 + 2] * 3 + k];
+        l[k] = fminf(a, fminf(b, c));
+        h[k] = fmaxf(a, fmaxf(b, c));
+        const float e = 1e-5f * (1.0f + fmaxf(fabsf(l[k]), fabsf(h[k])));
+        l[k] -= e;
+        h[k] += e;
+    }
+    lo[f] = make_float4(l[0], l[1], l[2], 0.0f);
+    hi[f] = make_float4(h[0], h[1], h[2], 0.0f);
+}
+
+__global__ void k_gather_tris(const float* __restrict__ verts, const uint32_t* __restrict__ faces,
+                              const uint32_t* __restrict__ order, uint32_t m, float4* __restrict__ tri)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t f = order[j];
+    const uint32_t i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    tri[(size_t)j * 3 + 0] = make_float4(verts[i0 * 3], verts[i0 * 3 + 1], verts[i0 * 3 + 2], __uint_as_float(f));
+    tri[(size_t)j * 3 + 1] = make_float4(verts[i1 * 3], verts[i1 * 3 + 1], verts[i1 * 3 + 2], 0.0f);
+    tri[(size_t)j * 3 + 2] = make_float4(verts[i2 * 3], verts[i2 * 3 + 1], verts[i2 * 3 + 2], 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int grt_create(grt_ctx** out, int device)
+{
+    if (!out) return GRT_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = "grt_create: no HIP device available (" + std::string(e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                       "); libgrt_hip has no CPU fallback";
+        return GRT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_err = "grt_create: device index out of range";
+        return GRT_ERR_INVALID;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    grt_ctx* c = new grt_ctx();
+    c->device = device;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc(&c->d_counters, 6 * sizeof(unsigned long long))) != hipSuccess) {
+        g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
+        delete c;
+        return GRT_ERR_HIP;
+    }
+    *out = c;
+    return GRT_OK;
+}
+
+static void free_gaussians(grt_ctx* c)
+{
+    (void)hipFree(c->d_pos); (void)hipFree(c->d_scale); (void)hipFree(c->d_quat); (void)hipFree(c->d_opacity);
+    (void)hipFree(c->d_sh); (void)hipFree(c->d_color0);
+    c->d_pos = c->d_scale = c->d_quat = c->d_opacity = c->d_sh = nullptr;
+    c->d_color0 = nullptr;
+    c->n = 0;
+    c->built = false;
+}
+
+static void free_meshes(grt_ctx* c)
+{
+    (void)hipFree(c->d_tri); (void)hipFree(c->d_faces); (void)hipFree(c->d_vnormals);
+    c->d_tri = nullptr; c->d_faces = nullptr; c->d_vnormals = nullptr;
+    c->n_faces = c->n_verts = 0;
+    free_bvh(&c->mbvh);
+}
+
+void grt_destroy(grt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_gaussians(c);
+    free_meshes(c);
+    free_bvh(&c->gbvh);
+    (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* grt_last_error(const grt_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int grt_set_option(grt_ctx* c, int option, int value)
+{
+    if (!c) return GRT_ERR_INVALID;
+    if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
+    else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
+    else { c->err = "grt_set_option: unknown option"; return GRT_ERR_INVALID; }
+    return GRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene
+// ------------------------------------------------------------------------------------------------
+int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
+{
+    if (!c || (n && (!g || !g->pos || !g->scale || !g->quat || !g->opacity || !g->sh))) {
+        if (c) c->err = "grt_upload_gaussians: null argument";
+        return GRT_ERR_INVALID;
+    }
+    if (n >= 0x7FFFFFFFull) { c->err = "grt_upload_gaussians: more than 2^31-1 particles"; return GRT_ERR_LIMIT; }
+    CHK(c, hipSetDevice(c->device));
+    CHK(c, hipStreamSynchronize(c->stream));
+    free_gaussians(c);
+    c->h_opacity.assign(g ? g->opacity : nullptr, g ? g->opacity + n : nullptr);
+    if (n == 0) return GRT_OK;
+    CHK(c, hipMalloc(&c->d_pos, n * 3 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_scale, n * 3 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_quat, n * 4 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_opacity, n * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_sh, n * 48 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_color0, n * sizeof(float4)));
+    CHK(c, hipMemcpyAsync(c->d_pos, g->pos, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_scale, g->scale, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_quat, g->quat, n * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_opacity, g->opacity, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_sh, g->sh, n * 48 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_color0, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_sh, (uint32_t)n,
+                       c->d_color0);
+    CHK(c, hipGetLastError());
+    CHK(c, hipStreamSynchronize(c->stream)); // host arrays are only borrowed for the call
+    c->n = n;
+    return GRT_OK;
+}
+
+int grt_build_bvh(grt_ctx* c, float alpha_min)
+{
+    if (!c) return GRT_ERR_INVALID;
+    CHK(c, hipSetDevice(c->device));
+    c->built = false;
+    c->alpha_min = alpha_min;
+    const uint32_t n = (uint32_t)c->n;
+    c->gbvh.n_prims = 0;
+    c->gbvh.root_ref = kNoRoot;
+    c->gbvh.height = 0;
+    if (n == 0) { c->built = true; return GRT_OK; }
+    // proxy half-width s = sqrtf(2 logf(opacity/alpha_min)) on the HOST, as the reference does
+    // (src/GaussianTracer.cpp:306) — keeps the libm-dependent value identical to the host libm's.
+    std::vector<float> s(n);
+    for (uint32_t i = 0; i < n; i++) s[i] = sqrtf(2.0f * logf(c->h_opacity[i] / alpha_min));
+    float* d_s = nullptr;
+    float4 *d_lo = nullptr, *d_hi = nullptr;
+    int rc = GRT_OK;
+    hipError_t e;
+    if ((e = hipMalloc(&d_s, n * sizeof(float))) != hipSuccess || (e = hipMalloc(&d_lo, n * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(&d_hi, n * sizeof(float4))) != hipSuccess) {
+        c->err = std::string("grt_build_bvh: hipMalloc: ") + hipGetErrorString(e);
+        rc = GRT_ERR_HIP;
+    }
+    if (rc == GRT_OK) {
+        (void)hipMemcpyAsync(d_s, s.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        (void)hipEventRecord(c->ev0, c->stream);
+        hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
+                           d_s, n, d_lo, d_hi);
+        rc = build_lbvh(d_lo, d_hi, n, &c->gbvh, c->stream, &c->err);
+    }
+    if (rc == GRT_OK && c->gbvh.n_prims) {
+        const uint32_t m = c->gbvh.n_prims;
+        if (c->cap_rec < m) {
+            (void)hipFree(c->d_rec);
+            c->d_rec = nullptr;
+            c->cap_rec = 0;
+            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4))) != hipSuccess) {
+                c->err = std::string("grt_build_bvh: hipMalloc(rec): ") + hipGetErrorString(e);
+                rc = GRT_ERR_HIP;
+            } else c->cap_rec = m;
+        }
+        if (rc == GRT_OK)
+            hipLaunchKernelGGL(k_gather_records, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale,
+                               c->d_quat, c->d_opacity, d_s, c->gbvh.order, m, c->d_rec);
+    }
+    if (rc == GRT_OK) {
+        (void)hipEventRecord(c->ev1, c->stream);
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { c->err = std::string("grt_build_bvh: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+        else (void)hipEventElapsedTime(&c->build_ms, c->ev0, c->ev1);
+    }
+    (void)hipFree(d_s); (void)hipFree(d_lo); (void)hipFree(d_hi);
+    c->have_timing = false;
+    if (rc == GRT_OK) c->built = true;
+    return rc;
+}
+
+int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
+{
+    if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
+    CHK(c, hipSetDevice(c->device));
+    CHK(c, hipStreamSynchronize(c->stream));
+    free_meshes(c);
+    // Flatten every primitive into one world-space soup; face indices are offset per mesh in the order
+    // given (reference: one instance per primitive, instanceId = order of creation,
+    // src/GaussianTracer.cpp:592-593; lowest (mesh, face) wins exact-t ties).
+    std::vector<float> v, nrm;
+    std::vector<uint32_t> f;
+    for (uint32_t k = 0; k < n_meshes; k++) {
+        const grt_mesh& m = meshes[k];
+        if ((m.nv && (!m.verts || !m.normals)) || (m.nf && !m.faces)) { c->err = "grt_set_meshes: null array"; return GRT_ERR_INVALID; }
+        const uint32_t base = (uint32_t)(v.size() / 3);
+        v.insert(v.end(), m.verts, m.verts + (size_t)m.nv * 3);
+        nrm.insert(nrm.end(), m.normals, m.normals + (size_t)m.nv * 3);
+        for (size_t i = 0; i < (size_t)m.nf * 3; i++) {
+            if (m.faces[i] >= m.nv) { c->err = "grt_set_meshes: face index out of range"; return GRT_ERR_INVALID; }
+            f.push_back(m.faces[i] + base);
+        }
+    }
+    const uint32_t nf = (uint32_t)(f.size() / 3), nv = (uint32_t)(v.size() / 3);
+    if (nf == 0) return GRT_OK;
+    float* d_verts = nullptr;
+    float4 *d_lo = nullptr, *d_hi = nullptr;
+    CHK(c, hipMalloc(&d_verts, (size_t)nv * 3 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_vnormals, (size_t)nv * 3 * sizeof(float)));
+    CHK(c, hipMalloc(&c->d_faces, (size_t)nf * 3 * sizeof(uint32_t)));
+    CHK(c, hipMalloc(&d_lo, (size_t)nf * sizeof(float4)));
+    CHK(c, hipMalloc(&d_hi, (size_t)nf * sizeof(float4)));
+    CHK(c, hipMemcpyAsync(d_verts, v.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_vnormals, nrm.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    CHK(c, hipMemcpyAsync(c->d_faces, f.data(), (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
+    int rc = build_lbvh(d_lo, d_hi, nf, &c->mbvh, c->stream, &c->err);
+    if (rc == GRT_OK) {
+        hipError_t e = hipMalloc(&c->d_tri, (size_t)nf * 3 * sizeof(float4));
+        if (e != hipSuccess) { c->err = std::string("grt_set_meshes: hipMalloc: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+    }
+    if (rc == GRT_OK) {
+        hipLaunchKernelGGL(k_gather_tris, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
+                           c->mbvh.order, nf, c->d_tri);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { c->err = std::string("grt_set_meshes: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+    }
+    (void)hipFree(d_verts); (void)hipFree(d_lo); (void)hipFree(d_hi);
+    if (rc != GRT_OK) { free_meshes(c); return rc; }
+    c->n_faces = nf;
+    c->n_verts = nv;
+    return GRT_OK;
+}
+
+int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
+{
+    if (!c || !o) return GRT_ERR_INVALID;
+    memset(o, 0, sizeof(*o));
+    o->n_particles = c->n;
+    o->n_proxies = c->gbvh.n_prims;
+    o->n_nodes = c->gbvh.n_prims ? c->gbvh.n_prims - 1 : 0;
+    o->height = c->gbvh.height;
+    o->mesh_faces = c->n_faces;
+    o->mesh_height = c->mbvh.height;
+    o->build_ms = c->build_ms;
+    for (int k = 0; k < 3; k++) { o->scene_lo[k] = c->gbvh.lo[k]; o->scene_hi[k] = c->gbvh.hi[k]; }
+    return GRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// render
+// ------------------------------------------------------------------------------------------------
+static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
+{
+    if (!c || !p) return GRT_ERR_INVALID;
+    if (!c->built) { c->err = "render: grt_build_bvh has not been called after the last upload"; return GRT_ERR_INVALID; }
+    if (p->sh_degree_max > 3) { c->err = "render: sh_degree_max must be 0..3"; return GRT_ERR_INVALID; }
+    if (p->type < 0 || p->type > 2) { c->err = "render: type must be MIRROR/NORMAL/GLASS"; return GRT_ERR_INVALID; }
+    if (!(p->t_min > 0.0f)) { c->err = "render: t_min must be > 0"; return GRT_ERR_INVALID; }
+    memset(a, 0, sizeof(*a));
+    a->p = *p;
+    a->rec = c->d_rec;
+    a->nodes = c->gbvh.nodes;
+    a->root_ref = c->gbvh.root_ref;
+    a->n_prox = c->gbvh.n_prims;
+    a->color0 = c->d_color0;
+    a->sh = c->d_sh;
+    a->mnodes = c->mbvh.nodes;
+    a->tri = c->d_tri;
+    a->mroot = c->n_faces ? c->mbvh.root_ref : kNoRoot;
+    a->n_faces = c->n_faces;
+    a->faces = c->d_faces;
+    a->vnormals = c->d_vnormals;
+    a->counters = c->opt_counters ? c->d_counters : nullptr;
+    return GRT_OK;
+}
+
+static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
+{
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    CHK(c, hipSetDevice(c->device));
+    if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, 6 * sizeof(unsigned long long), s));
+    const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
+    CHK(c, hipEventRecord(c->ev0, s));
+    int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &c->err);
+    CHK(c, hipEventRecord(c->ev1, s));
+    c->have_timing = (rc == GRT_OK);
+    return rc;
+}
+
+int grt_render(grt_ctx* c, const grt_params* p, uint8_t* d_rgb8, float* d_rgbf, uint32_t x0, uint32_t y0, uint32_t x1,
+               uint32_t y1, void* stream)
+{
+    RenderArgs a;
+    int rc = fill_common(c, p, &a);
+    if (rc != GRT_OK) return rc;
+    if (x1 > p->width || y1 > p->height || x0 > x1 || y0 > y1) { c->err = "grt_render: window outside the frame"; return GRT_ERR_INVALID; }
+    if (!d_rgb8 && !d_rgbf) { c->err = "grt_render: no output buffer"; return GRT_ERR_INVALID; }
+    a.out8 = d_rgb8; a.outf = d_rgbf;
+    a.mode = 0;
+    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
+    a.nbx = (x1 - x0 + 15) / 16;
+    a.nby = (y1 - y0 + 15) / 16;
+    a.n_blocks = a.nbx * a.nby;
+    return do_launch(c, a, stream);
+}
+
+int grt_render_tiles(grt_ctx* c, const grt_params* p, uint8_t* d_rgb8, float* d_rgbf, uint32_t tile_w, uint32_t tile_h,
+                     uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles, void* stream)
+{
+    RenderArgs a;
+    int rc = fill_common(c, p, &a);
+    if (rc != GRT_OK) return rc;
+    if (!tile_w || !tile_h || (tile_w % 16) || (tile_h % 16)) { c->err = "grt_render_tiles: tile size must be a multiple of 16"; return GRT_ERR_INVALID; }
+    if (!d_rgb8 && !d_rgbf) { c->err = "grt_render_tiles: no output buffer"; return GRT_ERR_INVALID; }
+    const uint32_t tiles_x = (p->width + tile_w - 1) / tile_w, tiles_y = (p->height + tile_h - 1) / tile_h;
+    if (n_tiles && (!tile_stride || (uint64_t)first_tile + (uint64_t)(n_tiles - 1) * tile_stride >= (uint64_t)tiles_x * tiles_y)) {
+        c->err = "grt_render_tiles: tile range outside the frame's tile grid";
+        return GRT_ERR_INVALID;
+    }
+    a.out8 = d_rgb8; a.outf = d_rgbf;
+    a.mode = 1;
+    a.tile_w = tile_w; a.tile_h = tile_h; a.first_tile = first_tile; a.tile_stride = tile_stride; a.n_tiles = n_tiles;
+    a.tiles_x = tiles_x;
+    a.nbx = tile_w / 16; a.nby = tile_h / 16;
+    a.n_blocks = n_tiles * a.nbx * a.nby;
+    return do_launch(c, a, stream);
+}
+
+int grt_render_rays(grt_ctx* c, const grt_params* p, const float* d_rays, uint64_t n, float* d_rgbf, void* stream)
+{
+    RenderArgs a;
+    int rc = fill_common(c, p, &a);
+    if (rc != GRT_OK) return rc;
+    if (n && (!d_rays || !d_rgbf)) { c->err = "grt_render_rays: null buffer"; return GRT_ERR_INVALID; }
+    if (n > 0xFFFFFFFFull * 64) { c->err = "grt_render_rays: too many rays"; return GRT_ERR_LIMIT; }
+    a.outf = d_rgbf;
+    a.mode = 2;
+    a.rays = d_rays; a.n_rays = n;
+    a.n_blocks = (uint32_t)((n + 255) / 256);
+    return do_launch(c, a, stream);
+}
+
+int grt_sync(grt_ctx* c)
+{
+    if (!c) return GRT_ERR_INVALID;
+    CHK(c, hipSetDevice(c->device));
+    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipGetLastError());
+    return GRT_OK;
+}
+
+int grt_get_counters(grt_ctx* c, grt_counters* out)
+{
+    if (!c || !out) return GRT_ERR_INVALID;
+    CHK(c, hipSetDevice(c->device));
+    CHK(c, hipDeviceSynchronize());
+    unsigned long long h[6];
+    CHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->rays = h[0]; out->segments = h[1]; out->hit_evals = h[2]; out->rounds = h[3];
+    out->node_visits = h[4]; out->proxy_tests = h[5];
+    return GRT_OK;
+}
+
+int grt_last_kernel_ms(grt_ctx* c, float* ms)
+{
+    if (!c || !ms) return GRT_ERR_INVALID;
+    if (!c->have_timing) { c->err = "grt_last_kernel_ms: no render has been launched"; return GRT_ERR_INVALID; }
+    CHK(c, hipSetDevice(c->device));
+    CHK(c, hipEventSynchronize(c->ev1));
+    CHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return GRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,321 @@
+// grt_bvh.hip — LBVH builder for gfx950 (replaces the closed OptiX accel build behind
+// GaussianTracer::createGaussianParticlesBVH / createGAS / buildAccelationStructure,
+// src/GaussianTracer.cpp:297-473 of the reference).
+//
+// Pipeline (all on the device, one stream):
+//   1. k_scene_bounds   centroid bounds + count of valid primitives (wave reduce -> ordered-int atomics)
+//   2. k_morton         63-bit Morton key of the box centroid (21 bits / axis); invalid => ~0 (sorts last)
+//   3. rocprim radix sort of (key, primitive index)
+//   4. k_leaf_boxes     boxes gathered into sorted order
+//   5. k_hierarchy      Karras 2012 internal nodes from the sorted keys (ties broken by index)
+//   6. k_refit_pass     bottom-up boxes, one launch per tree level: a node is finished in pass p only
+//                       from children finished in passes < p, so every hand-off crosses a kernel
+//                       boundary (no in-launch inter-workgroup visibility protocol needed);
+//                       the number of passes IS the tree height, which sizes the traversal stack.
+// The BVH only culls: boxes are inflated by 1e-5*(1+|coordinate|) so that the exact slab test in
+// grt_render.hip, not the box, decides every hit.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "grt_internal.h"
+
+namespace grt {
+
+#define HIPCHK(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = (x);                                                                          \
+        if (e_ != hipSuccess) {                                                                       \
+            if (err) *err = std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"; \
+            goto fail;                                                                                \
+        }                                                                                             \
+    } while (0)
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+
+// bounds[0..2] = min centroid (ordered uint), [3..5] = max, [6] = valid count
+__global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
+                               uint32_t* __restrict__ bounds)
+{
+    uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0}, cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 l = lo[i], h = hi[i];
+        if (l.x <= h.x) {
+            const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+            for (int k = 0; k < 3; k++) {
+                const uint32_t o = f2ord(c[k]);
+                mn[k] = min(mn[k], o);
+                mx[k] = max(mx[k], o);
+            }
+            cnt++;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; k++) {
+            mn[k] = min(mn[k], (uint32_t)__shfl_xor((int)mn[k], off));
+            mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], off));
+        }
+        cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&bounds[k], mn[k]);
+            atomicMax(&bounds[3 + k], mx[k]);
+        }
+        atomicAdd(&bounds[6], cnt);
+    }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v)
+{
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void k_morton(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
+                         const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys,
+                         uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 l = lo[i], h = hi[i];
+    uint64_t key = ~0ull;
+    if (l.x <= h.x) {
+        const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            const float a = ord2f(bounds[k]), b = ord2f(bounds[3 + k]);
+            const float ext = b - a;
+            float u = ext > 0.0f ? (c[k] - a) / ext : 0.0f;
+            u = fminf(fmaxf(u, 0.0f), 1.0f);
+            q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
+        }
+        key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    }
+    keys[i] = key;
+    vals[i] = i;
+}
+
+__global__ void k_leaf_boxes(const float4* __restrict__ lo, const float4* __restrict__ hi,
+                             const uint32_t* __restrict__ order, uint32_t m, float4* __restrict__ lb_lo,
+                             float4* __restrict__ lb_hi)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t i = order[j];
+    lb_lo[j] = lo[i];
+    lb_hi[j] = hi[i];
+}
+
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int m, int i, int j)
+{
+    if (j < 0 || j >= m) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ b));
+}
+
+// Karras, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees" (HPG 2012)
+__global__ void k_hierarchy(const uint64_t* __restrict__ keys, int m, float4* __restrict__ nodes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1) return;
+    const int d = (delta(keys, m, i, i + 1) - delta(keys, m, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, m, i, i - d);
+    int lmax = 2;
+    while (delta(keys, m, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, m, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, m, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, m, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const uint32_t c0 = (min(i, j) == gamma) ? ((uint32_t)gamma | kLeafBit) : (uint32_t)gamma;
+    const uint32_t c1 = (max(i, j) == gamma + 1) ? ((uint32_t)(gamma + 1) | kLeafBit) : (uint32_t)(gamma + 1);
+    nodes[(size_t)i * 4 + 3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ bool child_box(uint32_t c, uint32_t pass, const float4* __restrict__ nodes,
+                                          const uint32_t* __restrict__ level, const float4* __restrict__ lb_lo,
+                                          const float4* __restrict__ lb_hi, float lo[3], float hi[3])
+{
+    if (c & kLeafBit) {
+        const float4 l = lb_lo[c & ~kLeafBit], h = lb_hi[c & ~kLeafBit];
+        lo[0] = l.x; lo[1] = l.y; lo[2] = l.z;
+        hi[0] = h.x; hi[1] = h.y; hi[2] = h.z;
+        return true;
+    }
+    const uint32_t lv = level[c];
+    if (lv == 0 || lv >= pass) return false; // not finished before this launch
+    const float4 q0 = nodes[(size_t)c * 4], q1 = nodes[(size_t)c * 4 + 1], q2 = nodes[(size_t)c * 4 + 2];
+    lo[0] = fminf(q0.x, q1.z); lo[1] = fminf(q0.y, q1.w); lo[2] = fminf(q0.z, q2.x);
+    hi[0] = fmaxf(q0.w, q2.y); hi[1] = fmaxf(q1.x, q2.z); hi[2] = fmaxf(q1.y, q2.w);
+    return true;
+}
+
+__global__ void k_refit_pass(float4* __restrict__ nodes, uint32_t* __restrict__ level, int m, uint32_t pass,
+                             const float4* __restrict__ lb_lo, const float4* __restrict__ lb_hi)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1) return;
+    if (level[i] != 0) return;
+    const float4 q3 = nodes[(size_t)i * 4 + 3];
+    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+    float l0[3], h0[3], l1[3], h1[3];
+    if (!child_box(c0, pass, nodes, level, lb_lo, lb_hi, l0, h0)) return;
+    if (!child_box(c1, pass, nodes, level, lb_lo, lb_hi, l1, h1)) return;
+    nodes[(size_t)i * 4 + 0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
+    nodes[(size_t)i * 4 + 1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
+    nodes[(size_t)i * 4 + 2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
+    level[i] = pass;
+}
+
+void free_bvh(DevBvh* b)
+{
+    if (b->nodes) (void)hipFree(b->nodes);
+    if (b->order) (void)hipFree(b->order);
+    *b = DevBvh();
+}
+
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* out, hipStream_t stream,
+               std::string* err)
+{
+    uint32_t* d_bounds = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_level = nullptr;
+    float4 *d_lblo = nullptr, *d_lbhi = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    uint32_t h_bounds[7];
+    uint32_t m = 0;
+    const int B = 256;
+
+    out->n_prims = 0;
+    out->height = 0;
+    out->root_ref = kNoRoot;
+    if (n_in == 0) return GRT_OK;
+    if (n_in >= 0x7FFFFFFFu) {
+        if (err) *err = "build_lbvh: more than 2^31-1 primitives";
+        return GRT_ERR_LIMIT;
+    }
+
+    HIPCHK(hipMalloc(&d_bounds, 7 * sizeof(uint32_t)));
+    {
+        const uint32_t init[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    }
+    HIPCHK(hipMalloc(&d_keys, sizeof(uint64_t) * n_in));
+    HIPCHK(hipMalloc(&d_keys2, sizeof(uint64_t) * n_in));
+    HIPCHK(hipMalloc(&d_vals, sizeof(uint32_t) * n_in));
+    if (out->cap_order < n_in) {
+        if (out->order) (void)hipFree(out->order);
+        out->order = nullptr;
+        out->cap_order = 0;
+        HIPCHK(hipMalloc(&out->order, sizeof(uint32_t) * n_in));
+        out->cap_order = n_in;
+    }
+    {
+        const int grid = (int)std::min<uint32_t>((n_in + B - 1) / B, 2048u);
+        hipLaunchKernelGGL(k_scene_bounds, dim3(grid), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds);
+        hipLaunchKernelGGL(k_morton, dim3((n_in + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds, d_keys,
+                           d_vals);
+    }
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
+                                     stream));
+    HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
+    HIPCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
+                                     stream));
+    HIPCHK(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    m = h_bounds[6];
+    out->n_prims = m;
+    for (int k = 0; k < 3; k++) {
+        out->lo[k] = m ? ord2f(h_bounds[k]) : 0.f;
+        out->hi[k] = m ? ord2f(h_bounds[3 + k]) : 0.f;
+    }
+    if (m == 0) goto done;
+    if (m == 1) {
+        out->root_ref = 0u | kLeafBit;
+        goto done;
+    }
+    if (out->cap_nodes < (size_t)(m - 1)) {
+        if (out->nodes) (void)hipFree(out->nodes);
+        out->nodes = nullptr;
+        out->cap_nodes = 0;
+        HIPCHK(hipMalloc(&out->nodes, sizeof(float4) * 4 * (size_t)(m - 1)));
+        out->cap_nodes = m - 1;
+    }
+    HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
+    HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
+    HIPCHK(hipMalloc(&d_level, sizeof(uint32_t) * (m - 1)));
+    HIPCHK(hipMemsetAsync(d_level, 0, sizeof(uint32_t) * (m - 1), stream));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, out->order, m, d_lblo,
+                       d_lbhi);
+    hipLaunchKernelGGL(k_hierarchy, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, d_keys2, (int)m, out->nodes);
+    {
+        uint32_t pass = 0, root_level = 0;
+        while (root_level == 0) {
+            pass++;
+            if (pass > 4096) {
+                if (err) *err = "build_lbvh: refit did not converge";
+                goto fail_limit;
+            }
+            hipLaunchKernelGGL(k_refit_pass, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_level,
+                               (int)m, pass, d_lblo, d_lbhi);
+            // poll every few passes only (a 4-byte readback syncs the stream)
+            if (pass >= 8 && (pass & 3) == 0) {
+                HIPCHK(hipMemcpyAsync(&root_level, d_level, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            } else if (pass < 8 && m <= (1u << pass)) {
+                HIPCHK(hipMemcpyAsync(&root_level, d_level, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
+        }
+        out->height = root_level;
+        out->root_ref = 0;
+    }
+done:
+    HIPCHK(hipGetLastError());
+    (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    return GRT_OK;
+fail_limit:
+    (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    return GRT_ERR_LIMIT;
+fail:
+    (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    return GRT_ERR_HIP;
+}
+
+}  // namespace grt

@@ -1,0 +1,104 @@
+// grt_internal.h — structures shared by the translation units of libgrt_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/grt.h"
+
+namespace grt {
+
+// Child reference inside a BVH node: bit 31 set => leaf (low 31 bits = sorted primitive index),
+// else index of an internal node.
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoRoot = 0xFFFFFFFFu;
+
+// LBVH in traversal layout.  One 64-B record (4 x float4) per INTERNAL node holding the boxes of
+// its two children, so a node fetch decides both descents:
+//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
+//   q3 = (child0, child1, 0, 0) as raw bits
+struct DevBvh {
+    float4* nodes = nullptr;   // [(n_prims-1) * 4]
+    uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
+    uint32_t n_prims = 0;      // valid primitives (leaves)
+    uint32_t height = 0;       // levels of internal nodes (bounds the traversal stack)
+    uint32_t root_ref = kNoRoot;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    size_t cap_nodes = 0, cap_order = 0;
+};
+
+// Build an LBVH over n_in boxes (invalid primitives have lo.x > hi.x and are left out).
+// Returns GRT_OK or an error code (message in *err).
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* out, hipStream_t stream,
+               std::string* err);
+void free_bvh(DevBvh* b);
+
+// Everything the render kernel reads, passed by value.
+struct RenderArgs {
+    grt_params p;
+    // Gaussian scene
+    const float4* rec;    // [n_prox*4] Morton-sorted proxy records (see grt_api.hip: k_gather_records)
+    const float4* nodes;
+    uint32_t root_ref;
+    uint32_t n_prox;
+    const float4* color0; // [n_particles] degree-0 radiance by ORIGINAL particle id
+    const float* sh;      // [n_particles][16][3] by original id
+    // mesh scene
+    const float4* mnodes;
+    const float4* tri;    // [n_faces*3] sorted: (v0, face id bits) (v1,0) (v2,0)
+    uint32_t mroot;
+    uint32_t n_faces;
+    const uint32_t* faces;  // [nf][3]
+    const float* vnormals;  // [nv][3]
+    // outputs
+    uint8_t* out8;
+    float* outf;
+    // work mapping: 0 = window, 1 = tiles, 2 = ray buffer
+    uint32_t mode;
+    uint32_t x0, y0, x1, y1;
+    uint32_t nbx;           // 16x16 blocks per row (window) / per tile row (tiles)
+    uint32_t nby;           // per tile column (tiles)
+    uint32_t tile_w, tile_h, first_tile, tile_stride, n_tiles, tiles_x;
+    const float* rays;
+    uint64_t n_rays;
+    uint32_t n_blocks;
+    unsigned long long* counters; // 6 x u64 or nullptr
+};
+
+int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
+                  std::string* err);
+
+}  // namespace grt
+
+struct grt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int opt_counters = 0;
+    int opt_kernel = 0;
+    // uploaded attributes (original order)
+    uint64_t n = 0;
+    float *d_pos = nullptr, *d_scale = nullptr, *d_quat = nullptr, *d_opacity = nullptr, *d_sh = nullptr;
+    float4* d_color0 = nullptr;
+    std::vector<float> h_opacity;
+    // Gaussian BVH + records
+    float alpha_min = 0.01f;
+    grt::DevBvh gbvh;
+    float4* d_rec = nullptr;
+    size_t cap_rec = 0;
+    bool built = false;
+    float build_ms = 0.f;
+    // meshes
+    grt::DevBvh mbvh;
+    float4* d_tri = nullptr;
+    uint32_t* d_faces = nullptr;
+    float* d_vnormals = nullptr;
+    uint32_t n_faces = 0, n_verts = 0;
+    // instrumentation
+    unsigned long long* d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+};

@@ -1,0 +1,410 @@
+// grt_render.hip — the render kernel: raygen + mesh closest-hit + k-nearest Gaussian traversal +
+// integration, one launch per frame (replaces optixLaunch of shaders/tracer.cu:17-187 and the OptiX
+// RT-core traversal behind optixTrace, src/GaussianTracer.cpp:525-534).
+//
+// Mapping: one ray per lane; a wave64 is an 8x8 pixel tile (coherent rays), a 256-thread
+// workgroup a 16x16 block; workgroups are dealt to XCDs so that each XCD's L2 sees a contiguous
+// run of screen blocks.  Traversal is per-lane with a short stack in LDS (stack[level][thread],
+// conflict-free), near child first, far child deferred; the k = 7 hit buffer lives in registers
+// as 64-bit keys (t, particle id, entry<exit) + alpha.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "grt_device.h"
+#include "grt_internal.h"
+
+namespace grt {
+
+constexpr int K = 7;           // MaxNumHitPerTrace, shaders/tracer.cuh:11
+constexpr int kBlock = 256;
+
+struct Cnt {
+    uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0;
+};
+
+struct KBuf {
+    uint64_t key[K];
+    float alpha[K];
+};
+
+__device__ __forceinline__ void kbuf_insert(KBuf& kb, uint64_t key, float alpha)
+{
+    // same effect as the 7 compare-and-swap steps of __anyhit__anyhit (shaders/tracer.cu:124-146)
+    if (key >= kb.key[K - 1]) return;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (key < kb.key[i]) {
+            const uint64_t tk = kb.key[i];
+            const float ta = kb.alpha[i];
+            kb.key[i] = key;
+            kb.alpha[i] = alpha;
+            key = tk;
+            alpha = ta;
+        }
+    }
+}
+
+// one k-nearest round: traceGPs + __anyhit__ (shaders/tracer.cuh:289-326, shaders/tracer.cu:136-153)
+template <bool COUNT>
+__device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
+                                          const rayinv& ri, uint64_t last_key, float t_hi, KBuf& kb, Cnt& c)
+{
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        kb.key[i] = kKeyInvalid;
+        kb.alpha[i] = 0.0f;
+    }
+    const float t_lo = key_t(last_key);
+    float bound = t_hi; // nothing beyond the current k-th nearest hit can enter the buffer
+    uint32_t sp = 0;
+    uint32_t cur = a.root_ref;
+    while (true) {
+        if (cur & kLeafBit) {
+            const uint32_t idx = cur & ~kLeafBit;
+            const float4* __restrict__ r = a.rec + (size_t)idx * 4;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+            if (COUNT) c.proxy_tests++;
+            const f3 mu = mk3(r0.x, r0.y, r0.z);
+            m33 A;
+            A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+            A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+            A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+            const f3 o_g = matvec(A, sub3(o, mu));
+            const f3 d_g = matvec(A, d);
+            float te, tx;
+            if (proxy_slabs(o_g, d_g, r0.w, te, tx)) {
+                const bool in_e = (te >= t_lo) && (te < t_hi);
+                const bool in_x = (tx >= t_lo) && (tx < t_hi);
+                if (in_e || in_x) {
+                    // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357):
+                    // evaluated once, carried by the entry and the exit hit
+                    const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
+                    const uint32_t id = __float_as_uint(r2.w);
+                    if (in_e) {
+                        const uint64_t k = mk_key(te, id, 0);
+                        if (k > last_key) kbuf_insert(kb, k, alpha);
+                    }
+                    if (in_x) {
+                        const uint64_t k = mk_key(tx, id, 1);
+                        if (k > last_key) kbuf_insert(kb, k, alpha);
+                    }
+                    if (kb.key[K - 1] != kKeyInvalid) bound = key_t(kb.key[K - 1]);
+                }
+            }
+            if (sp == 0) break;
+            cur = stk[(--sp) * kBlock];
+        } else {
+            const float4* __restrict__ q = a.nodes + (size_t)cur * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (COUNT) c.node_visits++;
+            float n0, f0, n1, f1;
+            box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
+            box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);
+            const bool h0 = (n0 <= f0) && (f0 >= t_lo) && (n0 <= bound);
+            const bool h1 = (n1 <= f1) && (f1 >= t_lo) && (n1 <= bound);
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                stk[(sp++) * kBlock] = first0 ? c1 : c0;
+                cur = first0 ? c0 : c1;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                if (sp == 0) break;
+                cur = stk[(--sp) * kBlock];
+            }
+        }
+    }
+}
+
+// trace() — shaders/tracer.cuh:328-373
+template <bool COUNT>
+__device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
+                                                float t_min, float t_max, float& density, f3& radiance, Cnt& c)
+{
+    float T = 1.0f - density;
+    const float epsT = 1e-9f;
+    float lastT = t_min;
+    radiance = mk3(0.0f, 0.0f, 0.0f);
+    if (COUNT) c.segments++;
+    if (a.root_ref == kNoRoot) return; // no hittable particle: density unchanged
+    const f3 dn = normalize3(d);
+    const rayinv ri = mk_rayinv(o, d);
+    uint64_t last_key = mk_key(lastT + epsT, 0x7FFFFFFFu, 1);
+    const float t_hi = t_max + epsT;
+    const float minT = a.p.minTransmittance;
+    KBuf kb;
+    while (lastT <= t_max && T > minT) {
+        gps_round<COUNT>(a, stk, o, d, ri, last_key, t_hi, kb, c);
+        if (COUNT) c.rounds++;
+        if (kb.key[0] == kKeyInvalid) break;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if (kb.key[i] != kKeyInvalid && T > minT) {
+                if (COUNT) c.hit_evals++;
+                lastT = fmaxf(key_t(kb.key[i]), lastT);
+                const float hitAlpha = kb.alpha[i];
+                if (a.p.alpha_min < hitAlpha) {
+                    const uint32_t id = key_id(kb.key[i]);
+                    f3 L;
+                    if (a.p.sh_degree_max == 0) {
+                        const float4 cc = a.color0[id];
+                        L = mk3(cc.x, cc.y, cc.z);
+                    } else {
+                        L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max);
+                    }
+                    radiance = add3(radiance, mul3s(mul3s(L, T), hitAlpha));
+                    T *= (1.0f - hitAlpha);
+                }
+            }
+        }
+        if (kb.key[K - 1] == kKeyInvalid) break; // fewer than K hits left: the next round would be empty
+        last_key = kb.key[K - 1];
+    }
+    density = 1.0f - T;
+}
+
+// traceMesh: closest triangle in (tmin, tmax) — shaders/tracer.cuh:266-287
+struct MeshHit { bool hit; float t, u, v; uint32_t face; };
+
+template <bool COUNT>
+__device__ __forceinline__ MeshHit mesh_closest(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
+                                                float tmin, float tmax, Cnt& c)
+{
+    MeshHit best{false, 0.f, 0.f, 0.f, 0u};
+    if (a.mroot == kNoRoot) return best; // mesh_handle == 0 => miss
+    const rayinv ri = mk_rayinv(o, d);
+    uint32_t sp = 0, cur = a.mroot;
+    while (true) {
+        if (cur & kLeafBit) {
+            const float4* __restrict__ tr = a.tri + (size_t)(cur & ~kLeafBit) * 3;
+            const float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
+            const uint32_t face = __float_as_uint(t0.w);
+            float t, u, v;
+            if (tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, t, u, v)) {
+                const bool inside = (t > tmin) && (t < tmax);
+                const bool tie = best.hit && (t == best.t) && (face < best.face);
+                if (inside || tie) {
+                    best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
+                    tmax = t;
+                }
+            }
+            if (sp == 0) break;
+            cur = stk[(--sp) * kBlock];
+        } else {
+            const float4* __restrict__ q = a.mnodes + (size_t)cur * 4;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            if (COUNT) c.node_visits++;
+            float n0, f0, n1, f1;
+            box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
+            box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);
+            const bool h0 = (n0 <= f0) && (f0 >= tmin) && (n0 <= tmax);
+            const bool h1 = (n1 <= f1) && (f1 >= tmin) && (n1 <= tmax);
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                stk[(sp++) * kBlock] = first0 ? c1 : c0;
+                cur = first0 ? c0 : c1;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else {
+                if (sp == 0) break;
+                cur = stk[(--sp) * kBlock];
+            }
+        }
+    }
+    return best;
+}
+
+// getBarycentricNormal — shaders/tracer.cuh:167-185
+__device__ __forceinline__ f3 bary_normal(const RenderArgs& a, const MeshHit& h)
+{
+    const uint32_t i0 = a.faces[h.face * 3], i1 = a.faces[h.face * 3 + 1], i2 = a.faces[h.face * 3 + 2];
+    const f3 n0 = mk3(a.vnormals[i0 * 3], a.vnormals[i0 * 3 + 1], a.vnormals[i0 * 3 + 2]);
+    const f3 n1 = mk3(a.vnormals[i1 * 3], a.vnormals[i1 * 3 + 1], a.vnormals[i1 * 3 + 2]);
+    const f3 n2 = mk3(a.vnormals[i2 * 3], a.vnormals[i2 * 3 + 1], a.vnormals[i2 * 3 + 2]);
+    const float w0 = 1.0f - h.u - h.v, w1 = h.u, w2 = h.v;
+    return normalize3(add3(add3(mul3s(n0, w0), mul3s(n1, w1)), mul3s(n2, w2)));
+}
+
+// __raygen__raygeneration bounce loop + __closesthit__ + __miss__ (shaders/tracer.cu:58-106,112-122,155-187)
+template <bool COUNT>
+__device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, f3 curO, f3 curD, Cnt& c)
+{
+    enum { LastGaussianPass = 0, GaussianPass = 1, MeshPass = 2, Terminate = 3 }; // src/Parameters.h:85-91
+    f3 accumColor = mk3(0, 0, 0), directLight = mk3(0, 0, 0);
+    float accumAlpha = 0.0f, blocking = 0.0f, density = 0.0f;
+    uint32_t numBounces = 0, timeout = 0;
+    while (length3(curD) > 0.1f && numBounces < a.p.max_bounces) {
+        const f3 ray_o = curO, ray_d = curD;
+        int state = MeshPass;
+        const MeshHit mh = mesh_closest<COUNT>(a, stk, ray_o, ray_d, kTraceMeshTmin, kTraceMeshTmax, c);
+        f3 normal = mk3(0, 0, 0);
+        float seg_tmax = a.p.t_max; // LastGaussianPass traces to t_max (shaders/tracer.cu:70-75)
+        if (mh.hit) {
+            float t_hit = mh.t;
+            normal = bary_normal(a, mh);
+            f3 newDir = mk3(0, 0, 0);
+            state = GaussianPass;
+            seg_tmax = t_hit;
+            if (a.p.type == GRT_MIRROR) { // renderMirror, shaders/tracer.cuh:396-404
+                newDir = reflect3(ray_d, normal);
+                numBounces += 1;
+            } else if (a.p.type == GRT_NORMAL) { // renderNormal traces [t_min, t_hit] itself, shaders/tracer.cuh:406-429
+                state = Terminate;
+            } else if (a.p.type == GRT_GLASS) { // renderGlass, shaders/tracer.cuh:466-482
+                const float n1 = 1.0003f, n2 = 1.5f;
+                if (refract_dir(ray_d, normal, n2 / n1, newDir)) t_hit += kRefractionEpsShift;
+                else numBounces += 1;
+                seg_tmax = t_hit; // payload.t_hit carries the shifted value (shaders/tracer.cu:180)
+            }
+            curO = add3(ray_o, mul3s(ray_d, t_hit));
+            curD = newDir;
+        } else { // __miss__miss
+            curO = mk3(0, 0, 0);
+            curD = mk3(0, 0, 0);
+            state = LastGaussianPass;
+        }
+        // the single Gaussian segment of this iteration (one call site keeps the kernel small)
+        f3 rad;
+        trace_gaussians<COUNT>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c);
+        const float alpha = density;
+        if (state == Terminate) { // renderNormal, shaders/tracer.cuh:417-428
+            accumColor = add3(accumColor, rad);
+            accumAlpha += alpha;
+            const f3 normalColor = mul3s(add3(normal, mk3(1.0f, 1.0f, 1.0f)), 0.5f);
+            accumColor = add3(accumColor, mul3s(normalColor, 1.0f - alpha));
+            accumAlpha += (1.0f - alpha);
+            break;
+        }
+        if (state == LastGaussianPass) { // shaders/tracer.cu:68-82
+            directLight = mul3s(rad, alpha);
+            accumAlpha = clampf(accumAlpha + alpha, 0.0f, 1.0f);
+        } else { // shaders/tracer.cu:84-98
+            accumColor = add3(accumColor, mul3s(rad, 1.0f - accumAlpha));
+            accumAlpha = clampf(accumAlpha + alpha, 0.0f, 1.0f);
+            blocking = clampf(blocking + alpha, 0.0f, 1.0f);
+        }
+        accumColor = add3(accumColor, mul3s(directLight, 1.0f - blocking)); // shaders/tracer.cu:101
+        timeout += 1;
+        if (timeout > kTimeoutIterations) break;
+    }
+    return accumColor;
+}
+
+// workgroup -> screen block: consecutive workgroup ids go round-robin over the 8 XCDs; give each
+// XCD a contiguous run of blocks so neighbouring screen blocks share an L2 (speed only)
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t nb)
+{
+    const uint32_t q = nb >> 3, r = nb & 7u;
+    const uint32_t xcd = b & 7u, idx = b >> 3;
+    return xcd * q + min(xcd, r) + idx;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    Cnt c;
+    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+
+    if (a.mode == 2) { // ray buffer
+        const uint64_t i = (uint64_t)blk * kBlock + threadIdx.x;
+        if (i < a.n_rays) {
+            const float* r = a.rays + i * 6;
+            if (COUNT) c.rays++;
+            const f3 col = shade_ray<COUNT>(a, stk, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), c);
+            a.outf[i * 3] = col.x; a.outf[i * 3 + 1] = col.y; a.outf[i * 3 + 2] = col.z;
+        }
+    } else {
+        uint32_t px, py;
+        size_t out_idx;
+        bool in_frame;
+        if (a.mode == 0) { // window of the full frame
+            px = a.x0 + (blk % a.nbx) * 16u + lx;
+            py = a.y0 + (blk / a.nbx) * 16u + ly;
+            in_frame = (px < a.x1) && (py < a.y1);
+            out_idx = (size_t)py * a.p.width + px; // shaders/tracer.cuh:487
+        } else { // compact tile list
+            const uint32_t per_tile = a.nbx * a.nby;
+            const uint32_t j = blk / per_tile, sub = blk % per_tile;
+            const uint32_t tile = a.first_tile + j * a.tile_stride;
+            const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+            const uint32_t ox = (sub % a.nbx) * 16u + lx, oy = (sub / a.nbx) * 16u + ly;
+            px = tx * a.tile_w + ox;
+            py = ty * a.tile_h + oy;
+            in_frame = (px < a.p.width) && (py < a.p.height);
+            out_idx = ((size_t)j * a.tile_h + oy) * a.tile_w + ox;
+        }
+        bool write = in_frame || (a.mode == 1);
+        f3 col = mk3(0.0f, 0.0f, 0.0f);
+        if (in_frame) {
+            const f3 nU = mk3(-a.p.U[0], -a.p.U[1], -a.p.U[2]), nV = mk3(-a.p.V[0], -a.p.V[1], -a.p.V[2]);
+            const f3 W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
+            f3 dir;
+            bool have_ray = true;
+            if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+            else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+            if (have_ray) {
+                if (COUNT) c.rays++;
+                col = shade_ray<COUNT>(a, stk, mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]), dir, c);
+            }
+        }
+        if (write) {
+            if (a.outf) {
+                a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
+            }
+            if (a.out8) { // writeOutputBuffer, shaders/tracer.cuh:484-496
+                a.out8[out_idx * 3] = quantize8(col.x);
+                a.out8[out_idx * 3 + 1] = quantize8(col.y);
+                a.out8[out_idx * 3 + 2] = quantize8(col.z);
+            }
+        }
+    }
+
+    if (COUNT) {
+        uint32_t v[6] = {c.rays, c.segments, c.hit_evals, c.rounds, c.node_visits, c.proxy_tests};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+            if (lane == 0 && x) atomicAdd(&a.counters[k], (unsigned long long)x);
+        }
+    }
+}
+
+int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
+                  std::string* err)
+{
+    (void)kernel_variant;
+    if (a.n_blocks == 0) return GRT_OK;
+    const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
+    if (lds > 160 * 1024) {
+        if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
+        return GRT_ERR_LIMIT;
+    }
+    auto fn = count ? k_render<true> : k_render<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    hipLaunchKernelGGL(fn, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("k_render launch: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+
+}  // namespace grt

@@ -1,0 +1,169 @@
+/*
+ * grt.h — C ABI of libgrt_hip.so, the MI355X-native replacement for the OptiX pipeline behind
+ * GaussianTracer::render() (reference: Ray-Studio2/gaussian-ray-tracing).
+ *
+ * Plain C: pointers, sizes, PODs.  No HIP, torch, OptiX or C++ types in any signature
+ * (a hipStream_t crosses as void*; device pointers cross as void* / typed pointers).
+ * Every entry point returns GRT_OK (0) or a negative grt_status; grt_last_error(ctx) holds the
+ * text (the reference throws std::runtime_error with call text, src/Exception.h:19-80 — the C++
+ * facade gaussian-ray-tracing_amd/host/GaussianTracer.cpp converts codes back to exceptions).
+ *
+ * What each entry point replaces in the reference:
+ *   grt_create / grt_destroy      createContext..createSBT + dtor          src/GaussianTracer.cpp:85-295, 54-70
+ *   grt_upload_gaussians          particle upload in initializeParams      src/GaussianTracer.cpp:491-502
+ *   grt_build_bvh                 createGaussianParticlesBVH/createGAS/    src/GaussianTracer.cpp:297-317,
+ *                                 buildAccelationStructure (OptiX, closed)   319-399, 422-473
+ *   grt_set_meshes                createGAS+createIAS for primitives,      src/GaussianTracer.cpp:578-709
+ *                                 sendGeometryAttributesToDevice
+ *   grt_render                    render(): param upload + optixLaunch of  src/GaussianTracer.cpp:508-538,
+ *                                 raygen/anyhit/closesthit/miss              shaders/tracer.cu:17-187
+ *   grt_render_tiles              (new) screen-tile sharding for N GPUs    SURVEY.md §8(e)
+ *   grt_render_rays               (new) ray-buffer input for parity tests  SURVEY.md §7 hard part 1
+ *   grt_sync                      CUDA_SYNC_CHECK()                        src/GaussianTracer.cpp:537
+ *   grt_host_*                    host-side pieces the facade shares with ctypes users:
+ *                                 GaussianData::parse (src/GaussianData.cpp:25-132), Camera::UVWFrame
+ *                                 (src/Camera.cpp:3-13), Primitives (src/geometry/Primitives.cpp:6-216)
+ *
+ * Ownership: the library owns every device allocation it makes; the caller owns output buffers;
+ * host input arrays are borrowed for the duration of the call only.  A context is bound to one
+ * device and is not re-entrant; distinct contexts may be driven from distinct threads/processes.
+ */
+#ifndef GRT_H
+#define GRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRT_API __attribute__((visibility("default")))
+
+typedef struct grt_ctx grt_ctx;
+
+typedef enum {
+    GRT_OK = 0,
+    GRT_ERR_INVALID = -1,   /* bad argument / call order */
+    GRT_ERR_HIP = -2,       /* a HIP runtime call failed */
+    GRT_ERR_NO_DEVICE = -3, /* no usable GPU: the product path has no CPU fallback */
+    GRT_ERR_IO = -4,        /* file could not be read / parsed */
+    GRT_ERR_LIMIT = -5      /* scene exceeds a built-in limit (e.g. BVH height) */
+} grt_status;
+
+/* enum MeshType — src/Parameters.h:78-83 */
+enum { GRT_MIRROR = 0, GRT_NORMAL = 1, GRT_GLASS = 2 };
+
+/* Activated Gaussians, one host array per attribute (reference AoS GaussianParticle,
+ * src/GaussianData.h:12-20).  quat is (w,x,y,z), already normalised; scale and opacity are
+ * already exp()/sigmoid()-activated exactly as src/GaussianData.cpp:97-131 does on the host. */
+typedef struct {
+    const float* pos;     /* [n][3]  */
+    const float* scale;   /* [n][3]  */
+    const float* quat;    /* [n][4]  */
+    const float* opacity; /* [n]     */
+    const float* sh;      /* [n][16][3] : sh[k] = (f_rest_{k-1}, f_rest_{14+k}, f_rest_{29+k}), sh[0] = f_dc */
+} grt_gaussians;
+
+/* Triangle mesh already placed in world space by the caller (the facade applies
+ * Primitive::transform): verts[nv][3]; normals[nv][3] pre-multiplied by mat3(transform)
+ * (src/GaussianTracer.cpp:659-662); faces[nf][3]. */
+typedef struct {
+    const float* verts;
+    const float* normals;
+    uint32_t nv;
+    const uint32_t* faces;
+    uint32_t nf;
+} grt_mesh;
+
+/* struct Params — src/Parameters.h:42-74, minus the OptiX handles / device pointers the library
+ * now owns (handle, d_particles, mesh_handle, d_meshes, traceState, output_buffer). */
+typedef struct {
+    uint32_t width, height;
+    uint32_t sh_degree_max;
+    float eye[3], U[3], V[3], W[3];
+    float t_min, t_max, minTransmittance, alpha_min;
+    int32_t mode_fisheye;
+    int32_t type;         /* GRT_MIRROR / GRT_NORMAL / GRT_GLASS */
+    uint32_t max_bounces; /* reference constant MAX_BOUNCES = 32, shaders/tracer.cuh:13 */
+} grt_params;
+
+typedef struct {
+    uint64_t rays;        /* rays spawned (pixels; fisheye: r <= 1 only) */
+    uint64_t segments;    /* Gaussian trace() calls (primary + secondary segments) */
+    uint64_t hit_evals;   /* k-buffer entries consumed with T > minT (entry and exit both count) */
+    uint64_t rounds;      /* k-buffer traversal rounds (traceGPs equivalents) */
+    uint64_t node_visits; /* BVH nodes fetched (Gaussian BVH + mesh BVH) */
+    uint64_t proxy_tests; /* exact icosahedron-slab tests executed */
+} grt_counters;
+
+typedef struct {
+    uint64_t n_particles;   /* uploaded */
+    uint64_t n_proxies;     /* hittable (opacity > alpha_min) */
+    uint32_t n_nodes;       /* internal nodes of the Gaussian LBVH */
+    uint32_t height;        /* LBVH height (levels of internal nodes) */
+    uint32_t mesh_faces;
+    uint32_t mesh_height;
+    float build_ms;         /* device time of the last grt_build_bvh */
+    float scene_lo[3], scene_hi[3];
+} grt_bvh_info;
+
+enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
+       GRT_OPT_KERNEL = 2   /* traversal kernel variant (0 = default); see DESIGN.md */ };
+
+/* ---- context ---- */
+GRT_API int grt_create(grt_ctx** out, int device);
+GRT_API void grt_destroy(grt_ctx* ctx);
+GRT_API const char* grt_last_error(const grt_ctx* ctx); /* ctx may be NULL: last error of grt_create */
+GRT_API int grt_set_option(grt_ctx* ctx, int option, int value);
+
+/* ---- scene ---- */
+GRT_API int grt_upload_gaussians(grt_ctx* ctx, const grt_gaussians* host, uint64_t n);
+GRT_API int grt_build_bvh(grt_ctx* ctx, float alpha_min);
+GRT_API int grt_set_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_meshes);
+GRT_API int grt_get_bvh_info(const grt_ctx* ctx, grt_bvh_info* out);
+
+/* ---- render (all asynchronous on `stream`, a hipStream_t; NULL = the context's own stream) ----
+ * d_rgb8 : device uchar3 frame, row-major y*width+x (shaders/tracer.cuh:484-496), may be NULL
+ * d_rgbf : device float3 frame holding accumColor before clamp/quantise, may be NULL
+ * Window [x0,x1) x [y0,y1) restricts which pixels are traced and written (0,0,width,height = all). */
+GRT_API int grt_render(grt_ctx* ctx, const grt_params* p, uint8_t* d_rgb8, float* d_rgbf, uint32_t x0, uint32_t y0,
+                       uint32_t x1, uint32_t y1, void* stream);
+/* Tiles are numbered row-major over the ceil(width/tile_w) x ceil(height/tile_h) grid.  Renders
+ * tiles first_tile + j*tile_stride (j = 0..n_tiles-1) into COMPACT buffers [j][tile_h][tile_w][3];
+ * pixels of a border tile that fall outside the frame are written as 0. */
+GRT_API int grt_render_tiles(grt_ctx* ctx, const grt_params* p, uint8_t* d_rgb8, float* d_rgbf, uint32_t tile_w,
+                             uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
+                             void* stream);
+/* d_rays[n][6] = origin, direction (device); d_rgbf[n][3] */
+GRT_API int grt_render_rays(grt_ctx* ctx, const grt_params* p, const float* d_rays, uint64_t n, float* d_rgbf,
+                            void* stream);
+GRT_API int grt_sync(grt_ctx* ctx);
+GRT_API int grt_get_counters(grt_ctx* ctx, grt_counters* out); /* syncs; counters of the last render */
+/* device time (ms, HIP events on the launch stream) of the last render's kernel; syncs */
+GRT_API int grt_last_kernel_ms(grt_ctx* ctx, float* ms);
+
+/* ---- host helpers (no GPU needed) ---- */
+/* Raw 3DGS PLY columns -> activated attributes (src/GaussianData.cpp:97-131).  f_rest is [n][45]. */
+GRT_API int grt_host_activate(uint64_t n, const float* pos, const float* f_dc, const float* f_rest,
+                              const float* opacity_logit, const float* log_scale, const float* rot, float* out_pos,
+                              float* out_scale, float* out_quat, float* out_opacity, float* out_sh);
+/* Camera::UVWFrame (src/Camera.cpp:3-13) */
+GRT_API void grt_host_uvw_frame(const float eye[3], const float lookat[3], const float up[3], float fovy_deg,
+                                float aspect, float U[3], float V[3], float W[3]);
+/* Deterministic synthetic 3DGS scene: fills raw PLY columns. */
+GRT_API int grt_host_synth_scene(uint64_t seed, uint64_t n, float* pos, float* f_dc, float* f_rest,
+                                 float* opacity_logit, float* log_scale, float* rot);
+/* 3DGS PLY (binary little-endian or ascii; float properties looked up by name as
+ * src/GaussianData.cpp:27-92 does).  Two-call pattern: n_out only, then fill. */
+GRT_API int grt_host_ply_count(const char* path, uint64_t* n_out);
+GRT_API int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f_dc, float* f_rest,
+                              float* opacity_logit, float* log_scale, float* rot);
+GRT_API int grt_host_ply_write(const char* path, uint64_t n, const float* pos, const float* f_dc, const float* f_rest,
+                               const float* opacity_logit, const float* log_scale, const float* rot);
+GRT_API const char* grt_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRT_H */
