@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: Mrays/s and ms/frame at 1080p on a 1M-Gaussian scene
+(BASELINE.json metric, config C3), on 1..N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: every rank traces its share of the frame's 32x32 screen tiles (scene replicated,
+tiles dealt round-robin), the tile buffers are gathered to rank 0 over RCCL and un-permuted into the
+frame (N = 1: one full-frame launch, no collective).  The frame is fixed, so scaling is STRONG.
+Inputs (scene, BVH) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gaussian-ray-tracing_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (seed, n_gaussians, width, height, fisheye, mesh, max_bounces)   — BASELINE.json configs
+    "C1": (1, 10_000, 256, 256, False, False, 32),
+    "C2": (2, 100_000, 1280, 720, False, False, 32),
+    "C3": (3, 1_000_000, 1920, 1080, False, False, 32),
+    "C4": (3, 1_000_000, 1920, 1080, False, True, 2),
+    "C5": (5, 3_000_000, 3840, 2160, True, False, 32),
+}
+TILE = 32
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(cnt, pixels, sh_degree, float_out=False):
+    """Bytes the kernel's algorithm needs per frame: every node / proxy record fetch is
+    64 B (two child boxes + links, or mu/A/s/opacity/id) at the granularity the kernel issues it (per wave
+    for the wave-cooperative kernel's scalar loads, per lane for the per-lane kernel), every consumed hit
+    its colour (16 B at degree 0, 192 B of SH above), every pixel 3 B (+12 B float)."""
+    b_col = 16 if sh_degree == 0 else 192
+    return cnt["rec_fetches"] * 64 + cnt["hit_evals"] * b_col + pixels * (3 + (12 if float_out else 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--sh-degree", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
+    ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import grt
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    seed, n, W, H, fisheye, with_mesh, max_bounces = WORKLOADS[args.workload]
+    raw = grt.synth_scene(seed, n)
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    p = grt.default_params(W, H, center, sh_degree=args.sh_degree, fisheye=fisheye, mesh_type=grt.MIRROR,
+                           max_bounces=max_bounces)
+    tr = grt.Tracer(local_rank)
+    tr.set_option(grt.OPT_KERNEL, args.kernel)
+    t0 = time.time()
+    tr.upload(acts)
+    mesh = None
+    if with_mesh:
+        pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)  # src/GaussianTracer.cpp:630-638
+        mesh = grt.sphere_mesh(pos)
+        tr.set_meshes([mesh])
+    setup_s = time.time() - t0
+    info = tr.bvh_info()
+
+    # ---- work split ----
+    tx, ty = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    n_tiles = tx * ty
+    my_cnt = (n_tiles - rank + world - 1) // world if world > 1 else 0
+    max_cnt = (n_tiles + world - 1) // world
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    if world > 1:
+        mine = torch.zeros((max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        if world == 1:
+            tr.render(p, out_u8=frame, want_u8=True)
+        else:
+            tr.render_tiles(p, TILE, TILE, rank, world, my_cnt, out_u8=mine)
+            dist.gather(mine, gathered, dst=0)
+            if rank == 0:
+                g = torch.stack(gathered, 1).reshape(max_cnt * world, TILE, TILE, 3)[:n_tiles]  # tile t = j*world + r
+                img = g.reshape(ty, tx, TILE, TILE, 3).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, 3)
+                frame.copy_(img[:H, :W])
+
+    # ---- instrumented frame (outside the timed region): counters for rays and algorithmic bytes ----
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    if world == 1:
+        tr.render(p, out_u8=frame, want_u8=True)
+    else:
+        tr.render_tiles(p, TILE, TILE, rank, world, my_cnt, out_u8=mine)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    names = ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests", "rec_fetches")
+    cnt_t = torch.tensor([cnt[k] for k in names], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cnt_t)
+    tot = dict(zip(names, cnt_t.tolist()))
+    rays_per_frame = tot["segments"]  # primary rays + each secondary segment
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms.append(tr.last_kernel_ms())  # HIP events on the launch stream; syncs like the reference's render()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kernel_ms = float(km.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        # roofline of the dominant (only) kernel: this rank's launch
+        pix_mine = W * H if world == 1 else my_cnt * TILE * TILE
+        b_alg = algorithmic_bytes(cnt, pix_mine, args.sh_degree)
+        b_min = cnt["hit_evals"] * (44 + 12 * (args.sh_degree + 1) ** 2) + pix_mine * 3  # SURVEY §8(d) floor
+        achieved = b_alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.workload}_sh{args.sh_degree}_k{args.kernel}_n{world}"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (+ ms/frame) @1080p, 1M-Gaussian PLY", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n}-Gaussian synthetic 3DGS scene (seed {seed}), {W}x{H} "
+                                   f"{'fisheye' if fisheye else 'pinhole'}, SH degree {args.sh_degree}"
+                                   f"{', reflective sphere mesh, <=2 bounces' if with_mesh else ', no mesh'}",
+                       "tile": f"{TILE}x{TILE} round-robin over ranks, RCCL gather to rank 0" if world > 1 else "full frame, one launch",
+                       "rays_per_frame": rays_per_frame, "hit_evals_per_ray": round(tot["hit_evals"] / max(tot["segments"], 1), 2),
+                       "rounds_per_ray": round(tot["rounds"] / max(tot["segments"], 1), 2),
+                       "node_visits_per_ray": round(tot["node_visits"] / max(tot["segments"], 1), 1),
+                       "proxy_tests_per_ray": round(tot["proxy_tests"] / max(tot["segments"], 1), 1),
+                       "rec_fetches_per_ray": round(tot["rec_fetches"] / max(tot["segments"], 1), 2),
+                       "bvh_height": info["height"], "n_proxies": info["n_proxies"], "bvh_build_ms": round(info["build_ms"], 2),
+                       "setup_s": round(setup_s, 2), "kernel_variant": args.kernel},
+            "kernel_ms": round(kernel_ms, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "grt::k_render_wave<false>" if (args.kernel != 1 and not with_mesh) else "grt::k_render<false>", "algorithmic_bytes_per_launch": int(b_alg),
+                         "floor_bytes_per_launch": int(b_min),
+                         "floor_frac": round(b_min / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(acts, p, mesh, W, H)
+        if args.dump:
+            np.save(args.dump, frame.cpu().numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    tr.close()
+
+
+def cpu_baseline(acts, p, mesh, W, H):
+    """The CPU oracle (oracle/grt_oracle.c, kind 'port': the reference itself needs OptiX and cannot run on a
+    CPU) on a bounded sample of the same workload: the centred quarter-area crop of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from common import acts_to_particles, to_oracle_params
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)  # the GPU box's CPU share for one GPU
+    sc = O.Scene(acts_to_particles(acts))
+    if mesh is not None:
+        sc.set_mesh(*mesh)
+    cw, ch = W // 2, H // 2
+    win = ((W - cw) // 2, (H - ch) // 2, (W - cw) // 2 + cw, (H - ch) // 2 + ch)
+    t0 = time.perf_counter()
+    _, _, c = sc.render(to_oracle_params(p), window=win, threads=cores, want_u8=True, want_f32=False)
+    dt = time.perf_counter() - t0
+    sc.close()
+    return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"centred {cw}x{ch} crop of the same frame ({c['segments']} rays, {dt:.1f} s); "
+                      f"full-frame estimate {W * H / (c['segments'] / dt) * 1e3:.0f} ms/frame",
+            "hit_evals_per_ray": round(c["hit_evals"] / max(c["segments"], 1), 2)}
+
+
+if __name__ == "__main__":
+    main()

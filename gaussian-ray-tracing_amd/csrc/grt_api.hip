@@ -167,7 +167,7 @@ int grt_create(grt_ctx** out, int device)
     c->device = device;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess ||
         (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counters, 6 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&c->d_counters, kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
         g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
         delete c;
         return GRT_ERR_HIP;
@@ -415,7 +415,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
 {
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     CHK(c, hipSetDevice(c->device));
-    if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, 6 * sizeof(unsigned long long), s));
+    if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
     CHK(c, hipEventRecord(c->ev0, s));
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &c->err);
@@ -491,10 +491,10 @@ int grt_get_counters(grt_ctx* c, grt_counters* out)
     if (!c || !out) return GRT_ERR_INVALID;
     CHK(c, hipSetDevice(c->device));
     CHK(c, hipDeviceSynchronize());
-    unsigned long long h[6];
+    unsigned long long h[kNumCounters];
     CHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->rays = h[0]; out->segments = h[1]; out->hit_evals = h[2]; out->rounds = h[3];
-    out->node_visits = h[4]; out->proxy_tests = h[5];
+    out->node_visits = h[4]; out->proxy_tests = h[5]; out->rec_fetches = h[6];
     return GRT_OK;
 }
 

@@ -65,11 +65,13 @@ struct RenderArgs {
     const float* rays;
     uint64_t n_rays;
     uint32_t n_blocks;
-    unsigned long long* counters; // 6 x u64 or nullptr
+    unsigned long long* counters; // 7 x u64 or nullptr
 };
 
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
                   std::string* err);
+int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
+constexpr int kNumCounters = 7;
 
 }  // namespace grt
 

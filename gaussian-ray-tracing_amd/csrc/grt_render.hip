@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
             uint32_t x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
             if (lane == 0 && x) atomicAdd(&a.counters[k], (unsigned long long)x);
+            if (lane == 0 && x && k >= 4) atomicAdd(&a.counters[6], (unsigned long long)x); // one 64-B fetch per lane visit
         }
     }
 }
@@ -384,8 +385,13 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
                   std::string* err)
 {
-    (void)kernel_variant;
     if (a.n_blocks == 0) return GRT_OK;
+    const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 128);
+    if (kernel_variant == 2 && !wave_ok) {
+        if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";
+        return GRT_ERR_INVALID;
+    }
+    if (kernel_variant != 1 && wave_ok) return launch_render_wave(a, count, stream, err);
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     if (lds > 160 * 1024) {
         if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";

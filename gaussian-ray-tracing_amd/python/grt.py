@@ -26,7 +26,8 @@ class Params(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests")]
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests",
+                                          "rec_fetches")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -64,6 +65,14 @@ def lib():
     """Load libgrt_hip.so; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP/HSA runtime (torch/lib/libamdhip64.so); it must be the one the process
+        # initialises, so import torch BEFORE libgrt_hip.so resolves libamdhip64 (two runtimes opening the
+        # KFD in one process => "no ROCm-capable device is detected").  Stand-alone C/C++ users bind to
+        # /opt/rocm as usual.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise GrtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")

@@ -93,8 +93,10 @@ typedef struct {
     uint64_t segments;    /* Gaussian trace() calls (primary + secondary segments) */
     uint64_t hit_evals;   /* k-buffer entries consumed with T > minT (entry and exit both count) */
     uint64_t rounds;      /* k-buffer traversal rounds (traceGPs equivalents) */
-    uint64_t node_visits; /* BVH nodes fetched (Gaussian BVH + mesh BVH) */
+    uint64_t node_visits; /* BVH node box tests by live rays (Gaussian BVH + mesh BVH) */
     uint64_t proxy_tests; /* exact icosahedron-slab tests executed */
+    uint64_t rec_fetches; /* 64-B node/proxy record fetches at the granularity the kernel loads them:
+                             per lane in the per-lane kernel, per wave (scalar load) in the wave kernel */
 } grt_counters;
 
 typedef struct {
@@ -109,7 +111,8 @@ typedef struct {
 } grt_bvh_info;
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
-       GRT_OPT_KERNEL = 2   /* traversal kernel variant (0 = default); see DESIGN.md */ };
+       GRT_OPT_KERNEL = 2   /* 0 = auto (wave-cooperative kernel for mesh-free frames, per-lane otherwise),
+                               1 = force the per-lane kernel, 2 = force the wave kernel (error if illegal) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
