@@ -57,6 +57,7 @@ def main():
 
     import torch
     import grt
+    import tiles
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,10 +97,9 @@ def main():
     info = tr.bvh_info()
 
     # ---- work split ----
-    tx, ty = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    tx, ty = tiles.grid(W, H, TILE)
     n_tiles = tx * ty
-    my_cnt = (n_tiles - rank + world - 1) // world if world > 1 else 0
-    max_cnt = (n_tiles + world - 1) // world
+    _, _, my_cnt, max_cnt = tiles.my_tiles(n_tiles, world, rank)
     frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     if world > 1:
         mine = torch.zeros((max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=dev)
@@ -110,11 +110,9 @@ def main():
             tr.render(p, out_u8=frame, want_u8=True)
         else:
             tr.render_tiles(p, TILE, TILE, rank, world, my_cnt, out_u8=mine)
-            dist.gather(mine, gathered, dst=0)
+            dist.gather(mine, gathered, dst=0)  # RCCL: 7 peers -> 7 distinct xGMI links into rank 0, <= 0.8 MB each
             if rank == 0:
-                g = torch.stack(gathered, 1).reshape(max_cnt * world, TILE, TILE, 3)[:n_tiles]  # tile t = j*world + r
-                img = g.reshape(ty, tx, TILE, TILE, 3).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, 3)
-                frame.copy_(img[:H, :W])
+                frame.copy_(tiles.assemble(gathered, W, H, TILE))
 
     # ---- instrumented frame (outside the timed region): counters for rays and algorithmic bytes ----
     tr.set_option(grt.OPT_COUNTERS, 1)

@@ -1,0 +1,19 @@
+#include "HipGlue.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace hipglue {
+static void chk(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void* streamCreate() { hipStream_t s; chk(hipStreamCreate(&s), "hipStreamCreate"); return s; }
+void streamDestroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+void streamSync(void* s) { chk(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize"); }
+void* deviceAlloc(size_t bytes) { void* p = nullptr; chk(hipMalloc(&p, bytes), "hipMalloc"); return p; }
+void deviceFree(void* p) { if (p) (void)hipFree(p); }
+void copyToHost(void* dst, const void* src, size_t bytes) { chk(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy"); }
+}

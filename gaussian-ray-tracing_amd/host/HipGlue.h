@@ -1,0 +1,12 @@
+// HipGlue.h — the only place the host facade touches the HIP runtime (kept in its own translation unit so
+// that the facade's float3/uchar3 never meet HIP's vector types).
+#pragma once
+#include <cstddef>
+namespace hipglue {
+void* streamCreate();
+void  streamDestroy(void* stream);
+void  streamSync(void* stream);
+void* deviceAlloc(size_t bytes);
+void  deviceFree(void* p);
+void  copyToHost(void* dst, const void* src, size_t bytes);
+}

@@ -1,0 +1,95 @@
+"""The C++ facade (GaussianTracer mirror) through the headless CLI gaussian-ray-tracing_amd/grt_render."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import grt
+import oracle as O
+from common import acts_to_particles, to_oracle_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gaussian-ray-tracing_amd", "grt_render")
+
+
+def _read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"255"
+        return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)[::-1]  # file is top-down, frame row 0 = bottom
+
+
+def _scene(tmp_path, seed=12, n=3000):
+    raw = grt.synth_scene(seed, n)
+    raw["scale"] = raw["scale"] + np.float32(0.6)
+    ply = str(tmp_path / "scene.ply")
+    grt.write_ply(ply, raw)
+    return ply, grt.activate(raw)
+
+
+def test_cli_exists_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ply, _ = _scene(tmp_path, n=50)
+    r = subprocess.run([CLI, "-p", ply, "--width", "32", "--height", "32"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    r = subprocess.run([CLI, "-p", str(tmp_path / "missing.ply")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_frame_matches_oracle(tmp_path):
+    ply, acts = _scene(tmp_path)
+    out = str(tmp_path / "f.ppm")
+    r = subprocess.run([CLI, "-p", ply, "--width", "160", "--height", "96", "--out", out, "--bench", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Mrays/s" in r.stdout
+    p = grt.default_params(160, 96, grt.gaussian_center(acts["pos"]))
+    sc = O.Scene(acts_to_particles(acts))
+    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    got = _read_ppm(out)
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and cnt["hit_evals"] > 160 * 96
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sphere", "obj"])
+def test_cli_mirror_mesh_matches_oracle(tmp_path, kind):
+    ply, acts = _scene(tmp_path)
+    out = str(tmp_path / "f.ppm")
+    center = grt.gaussian_center(acts["pos"])
+    eye = np.float32([0, 0, 3])
+    pos = (center * np.float32(0.25) + eye * np.float32(0.75)).astype(np.float32)  # src/GaussianTracer.cpp:580-588
+    args = [CLI, "-p", ply, "--width", "128", "--height", "96", "--out", out, "--type", "mirror", "--bounces", "3"]
+    if kind == "sphere":
+        v, n, f = grt.sphere_mesh(pos)  # numpy sin/cos may differ from sinf in the last bit: geometry differs by ulps
+        args += ["--sphere"]
+        tol_frac = 2e-3
+    else:
+        v0, n0, f = grt.sphere_mesh((0, 0, 0), tess_u=40, tess_v=20)
+        obj = str(tmp_path / "m.obj")
+        with open(obj, "w") as fh:  # the loader flips Y of positions and normals (Primitives.cpp:175,179)
+            for a in v0:
+                fh.write(f"v {float(a[0])!r} {float(-a[1])!r} {float(a[2])!r}\n")
+            for a in n0:
+                fh.write(f"vn {float(a[0])!r} {float(-a[1])!r} {float(a[2])!r}\n")
+            for t in f:
+                fh.write("f " + " ".join(f"{i + 1}//{i + 1}" for i in t) + "\n")
+        args += ["--obj", obj]
+        # the loader emits one vertex per face corner, in file order
+        v = (v0[f.reshape(-1)] + pos[None]).astype(np.float32); n = n0[f.reshape(-1)]
+        f = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+        tol_frac = 0.0
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    p = grt.default_params(128, 96, center, mesh_type=grt.MIRROR, max_bounces=3)
+    sc = O.Scene(acts_to_particles(acts))
+    sc.set_mesh(v, n, f)
+    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    got = _read_ppm(out)
+    bad = (np.abs(got.astype(int) - ref.astype(int)) > 1).any(-1).mean()
+    assert bad <= tol_frac, bad
+    assert cnt["segments"] > cnt["rays"]
