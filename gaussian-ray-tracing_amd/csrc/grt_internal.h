@@ -71,6 +71,7 @@ struct RenderArgs {
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
                   std::string* err);
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
+int launch_render_stream(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 7;
 
 }  // namespace grt

@@ -386,12 +386,13 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
                   std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
-    const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 128);
+    const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
+    if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, stream, err);
     if (kernel_variant == 2 && !wave_ok) {
         if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";
         return GRT_ERR_INVALID;
     }
-    if (kernel_variant != 1 && wave_ok) return launch_render_wave(a, count, stream, err);
+    if (kernel_variant != 1 && kernel_variant != 3 && wave_ok) return launch_render_wave(a, count, stream, err);
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     if (lds > 160 * 1024) {
         if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";

@@ -112,7 +112,8 @@ typedef struct {
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
        GRT_OPT_KERNEL = 2   /* 0 = auto (wave-cooperative kernel for mesh-free frames, per-lane otherwise),
-                               1 = force the per-lane kernel, 2 = force the wave kernel (error if illegal) */ };
+                               1 = force the per-lane kernel, 2 = force the wave kernel (error if illegal),
+                               3 = single-pass streaming wave kernel where legal, per-lane otherwise */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
