@@ -34,6 +34,16 @@ TILE = 32
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def kernel_name(variant, with_mesh, n_proxies, sh_degree):
+    """Which kernel grt_render dispatches to (csrc/grt_render.hip: launch_render)."""
+    sh = "true" if sh_degree > 0 else "false"
+    if with_mesh or variant == 1:
+        return "grt::k_render<false>"
+    if variant == 3 or (variant == 0 and n_proxies >= 500000):
+        return f"grt::k_render_stream<false, {sh}>"
+    return f"grt::k_render_wave<false, {sh}>"
+
+
 def algorithmic_bytes(cnt, pixels, sh_degree, float_out=False):
     """Bytes the kernel's algorithm needs per frame: every node / proxy record fetch is
     64 B (two child boxes + links, or mu/A/s/opacity/id) at the granularity the kernel issues it (per wave
@@ -186,7 +196,7 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "grt::k_render_wave<false>" if (args.kernel != 1 and not with_mesh) else "grt::k_render<false>", "algorithmic_bytes_per_launch": int(b_alg),
+                         "kernel": kernel_name(args.kernel, with_mesh, info["n_proxies"], args.sh_degree), "algorithmic_bytes_per_launch": int(b_alg),
                          "floor_bytes_per_launch": int(b_min),
                          "floor_frac": round(b_min / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
@@ -217,14 +227,14 @@ def cpu_baseline(acts, p, mesh, W, H):
     sc = O.Scene(acts_to_particles(acts))
     if mesh is not None:
         sc.set_mesh(*mesh)
-    cw, ch = W // 2, H // 2
+    cw, ch = (W, H) if W * H <= 1920 * 1080 else (W // 2, H // 2)
     win = ((W - cw) // 2, (H - ch) // 2, (W - cw) // 2 + cw, (H - ch) // 2 + ch)
     t0 = time.perf_counter()
     _, _, c = sc.render(to_oracle_params(p), window=win, threads=cores, want_u8=True, want_f32=False)
     dt = time.perf_counter() - t0
     sc.close()
     return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"centred {cw}x{ch} crop of the same frame ({c['segments']} rays, {dt:.1f} s); "
+            "sample": f"{'whole' if (cw, ch) == (W, H) else 'centred'} {cw}x{ch} window of the same frame ({c['segments']} rays, {dt:.1f} s); "
                       f"full-frame estimate {W * H / (c['segments'] / dt) * 1e3:.0f} ms/frame",
             "hit_evals_per_ray": round(c["hit_evals"] / max(c["segments"], 1), 2)}
 

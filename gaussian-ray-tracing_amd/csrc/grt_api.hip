@@ -217,6 +217,14 @@ int grt_set_option(grt_ctx* c, int option, int value)
     if (!c) return GRT_ERR_INVALID;
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
+    else if (option == GRT_OPT_SWIZZLE) {
+        if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
+        c->opt_swizzle = value;
+    }
+    else if (option == GRT_OPT_LEAF_MAX) {
+        if (value < 1 || value > (int)kLeafMaxPrims) { c->err = "GRT_OPT_LEAF_MAX must be 1..8"; return GRT_ERR_INVALID; }
+        c->opt_leaf_max = value; // takes effect at the next grt_build_bvh / grt_set_meshes
+    }
     else { c->err = "grt_set_option: unknown option"; return GRT_ERR_INVALID; }
     return GRT_OK;
 }
@@ -284,7 +292,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, n, &c->gbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, &c->gbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
@@ -349,7 +357,7 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
     CHK(c, hipMemcpyAsync(c->d_vnormals, nrm.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     CHK(c, hipMemcpyAsync(c->d_faces, f.data(), (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
-    int rc = build_lbvh(d_lo, d_hi, nf, &c->mbvh, c->stream, &c->err);
+    int rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, &c->mbvh, c->stream, &c->err);
     if (rc == GRT_OK) {
         hipError_t e = hipMalloc(&c->d_tri, (size_t)nf * 3 * sizeof(float4));
         if (e != hipSuccess) { c->err = std::string("grt_set_meshes: hipMalloc: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
@@ -408,6 +416,7 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     a->faces = c->d_faces;
     a->vnormals = c->d_vnormals;
     a->counters = c->opt_counters ? c->d_counters : nullptr;
+    a->swizzle_chunk = (uint32_t)c->opt_swizzle;
     return GRT_OK;
 }
 

@@ -140,7 +140,8 @@ __device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int m, i
 }
 
 // Karras, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees" (HPG 2012)
-__global__ void k_hierarchy(const uint64_t* __restrict__ keys, int m, float4* __restrict__ nodes)
+__global__ void k_hierarchy(const uint64_t* __restrict__ keys, int m, float4* __restrict__ nodes,
+                            uint2* __restrict__ range)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m - 1) return;
@@ -162,6 +163,27 @@ __global__ void k_hierarchy(const uint64_t* __restrict__ keys, int m, float4* __
     const uint32_t c0 = (min(i, j) == gamma) ? ((uint32_t)gamma | kLeafBit) : (uint32_t)gamma;
     const uint32_t c1 = (max(i, j) == gamma + 1) ? ((uint32_t)(gamma + 1) | kLeafBit) : (uint32_t)(gamma + 1);
     nodes[(size_t)i * 4 + 3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), 0.0f, 0.0f);
+    range[i] = make_uint2((uint32_t)min(i, j), (uint32_t)max(i, j));
+}
+
+// Collapse bottom subtrees: a child that is an internal node covering <= leaf_max sorted primitives becomes a
+// leaf RANGE reference (the nodes below it are simply never reached).  Every Karras node covers a contiguous
+// range of the sorted order, so no data moves.
+__global__ void k_collapse(float4* __restrict__ nodes, const uint2* __restrict__ range, int m, uint32_t leaf_max)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1) return;
+    float4 q3 = nodes[(size_t)i * 4 + 3];
+    uint32_t c[2] = {__float_as_uint(q3.x), __float_as_uint(q3.y)};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (!(c[k] & kLeafBit)) {
+            const uint2 r = range[c[k]];
+            const uint32_t n = r.y - r.x + 1u;
+            if (n <= leaf_max) c[k] = kLeafBit | ((n - 1u) << 28) | r.x;
+        }
+    }
+    nodes[(size_t)i * 4 + 3] = make_float4(__uint_as_float(c[0]), __uint_as_float(c[1]), 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ bool child_box(uint32_t c, uint32_t pass, const float4* __restrict__ nodes,
@@ -206,9 +228,10 @@ void free_bvh(DevBvh* b)
     *b = DevBvh();
 }
 
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* out, hipStream_t stream,
-               std::string* err)
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, DevBvh* out,
+               hipStream_t stream, std::string* err)
 {
+    uint2* d_range = nullptr;
     uint32_t* d_bounds = nullptr;
     uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
     uint32_t *d_vals = nullptr, *d_level = nullptr;
@@ -223,8 +246,9 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* ou
     out->height = 0;
     out->root_ref = kNoRoot;
     if (n_in == 0) return GRT_OK;
-    if (n_in >= 0x7FFFFFFFu) {
-        if (err) *err = "build_lbvh: more than 2^31-1 primitives";
+    leaf_max = std::max(1u, std::min(leaf_max, kLeafMaxPrims));
+    if (n_in > kLeafIndexMask) {
+        if (err) *err = "build_lbvh: more than 2^28 primitives";
         return GRT_ERR_LIMIT;
     }
 
@@ -263,8 +287,8 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* ou
         out->hi[k] = m ? ord2f(h_bounds[3 + k]) : 0.f;
     }
     if (m == 0) goto done;
-    if (m == 1) {
-        out->root_ref = 0u | kLeafBit;
+    if (m <= leaf_max) { // the whole scene is one leaf range
+        out->root_ref = kLeafBit | ((m - 1u) << 28);
         goto done;
     }
     if (out->cap_nodes < (size_t)(m - 1)) {
@@ -277,10 +301,11 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* ou
     HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
     HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
     HIPCHK(hipMalloc(&d_level, sizeof(uint32_t) * (m - 1)));
+    HIPCHK(hipMalloc(&d_range, sizeof(uint2) * (m - 1)));
     HIPCHK(hipMemsetAsync(d_level, 0, sizeof(uint32_t) * (m - 1), stream));
     hipLaunchKernelGGL(k_leaf_boxes, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, out->order, m, d_lblo,
                        d_lbhi);
-    hipLaunchKernelGGL(k_hierarchy, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, d_keys2, (int)m, out->nodes);
+    hipLaunchKernelGGL(k_hierarchy, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, d_keys2, (int)m, out->nodes, d_range);
     {
         uint32_t pass = 0, root_level = 0;
         while (root_level == 0) {
@@ -303,18 +328,21 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* ou
         out->height = root_level;
         out->root_ref = 0;
     }
+    if (leaf_max > 1)
+        hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
+    HIPCHK(hipStreamSynchronize(stream));
 done:
     HIPCHK(hipGetLastError());
     (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
-    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level); (void)hipFree(d_range);
     return GRT_OK;
 fail_limit:
     (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
-    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level); (void)hipFree(d_range);
     return GRT_ERR_LIMIT;
 fail:
     (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);
-    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level);
+    (void)hipFree(d_tmp); (void)hipFree(d_lblo); (void)hipFree(d_lbhi); (void)hipFree(d_level); (void)hipFree(d_range);
     return GRT_ERR_HIP;
 }
 

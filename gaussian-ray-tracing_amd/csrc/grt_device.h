@@ -135,6 +135,17 @@ __device__ __forceinline__ bool proxy_slabs(f3 o_g, f3 d_g, float s, float& t_en
     return t_entry <= t_exit;
 }
 
+// Conservative pre-test (culling only, never decides a hit): can the ray touch the sphere that circumscribes
+// the proxy icosahedron in Gaussian space (circumradius / inradius = 1.2584086)?  The 4e-6 slack covers the
+// fp32 rounding of the three dot products; when |o_g| is so large that the slack exceeds R^2 the test simply
+// passes everything.
+__device__ __forceinline__ bool proxy_sphere_maybe(f3 o_g, f3 d_g, float s)
+{
+    const float R = 1.2585f * s;
+    const float b = dot3(o_g, d_g), aa = dot3(d_g, d_g), cc = dot3(o_g, o_g) - R * R;
+    return (cc <= 0.0f) || (b * b * (1.0f + 4e-6f) >= aa * cc);
+}
+
 // computeResponse — shaders/tracer.cuh:187-214, given o_g = A(o-mu), d_g = A d already formed
 __device__ __forceinline__ float response_from(const m33& A, f3 mu, f3 o, f3 d, f3 o_g, f3 d_g)
 {
@@ -279,6 +290,30 @@ __device__ __forceinline__ void box_interval(float lx, float ly, float lz, float
     const float z0 = __builtin_fmaf(lz, r.inv.z, r.oinv.z), z1 = __builtin_fmaf(hz, r.inv.z, r.oinv.z);
     tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+}
+
+// Euclidean distance from point o to an axis-aligned box (0 inside)
+__device__ __forceinline__ float box_dist(float lx, float ly, float lz, float hx, float hy, float hz, f3 o)
+{
+    const float dx = fmaxf(fmaxf(lx - o.x, o.x - hx), 0.0f);
+    const float dy = fmaxf(fmaxf(ly - o.y, o.y - hy), 0.0f);
+    const float dz = fmaxf(fmaxf(lz - o.z, o.z - hz), 0.0f);
+    return sqrtf(__builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz)));
+}
+
+// Workgroup -> screen-block map.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs (speed only,
+// never correctness).  With chunk = C, XCD x works on runs of C consecutive screen blocks: blocks
+// [g*8C + x*C, g*8C + (x+1)*C) for g = 0,1,...  Small C keeps per-XCD L2 locality (neighbouring tiles touch the
+// same BVH nodes / proxies) while interleaving XCDs finely enough to balance the spatially varying ray cost.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t nb, uint32_t chunk)
+{
+    if (chunk == 0u) return b;
+    const uint32_t group = 8u * chunk;
+    const uint32_t full = (nb / group) * group; // blocks beyond the last full group keep their id
+    if (b >= full) return b;
+    const uint32_t g = b / group, r = b % group;
+    const uint32_t xcd = r & 7u, k = r >> 3;      // k-th block this XCD receives inside the group
+    return g * group + xcd * chunk + k;
 }
 
 // 64-bit hit key: (t bits, particle id, entry<exit) — decision (iv) total order

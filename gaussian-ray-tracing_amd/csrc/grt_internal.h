@@ -11,9 +11,14 @@
 
 namespace grt {
 
-// Child reference inside a BVH node: bit 31 set => leaf (low 31 bits = sorted primitive index),
+// Child reference inside a BVH node: bit 31 set => leaf RANGE of sorted primitives: bits 0-27 = first
+// index, bits 28-30 = count-1 (bottom subtrees of <= leaf_max primitives are collapsed into one leaf);
 // else index of an internal node.
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLeafIndexMask = 0x0FFFFFFFu;
+constexpr uint32_t kLeafMaxPrims = 8u;
+__host__ __device__ inline uint32_t leaf_first(uint32_t ref) { return ref & kLeafIndexMask; }
+__host__ __device__ inline uint32_t leaf_count(uint32_t ref) { return ((ref >> 28) & 7u) + 1u; }
 constexpr uint32_t kNoRoot = 0xFFFFFFFFu;
 
 // LBVH in traversal layout.  One 64-B record (4 x float4) per INTERNAL node holding the boxes of
@@ -32,8 +37,8 @@ struct DevBvh {
 
 // Build an LBVH over n_in boxes (invalid primitives have lo.x > hi.x and are left out).
 // Returns GRT_OK or an error code (message in *err).
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* out, hipStream_t stream,
-               std::string* err);
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, DevBvh* out,
+               hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
 
 // Everything the render kernel reads, passed by value.
@@ -65,6 +70,7 @@ struct RenderArgs {
     const float* rays;
     uint64_t n_rays;
     uint32_t n_blocks;
+    uint32_t swizzle_chunk; // see xcd_swizzle (grt_device.h); 0 = identity
     unsigned long long* counters; // 7 x u64 or nullptr
 };
 
@@ -82,6 +88,8 @@ struct grt_ctx {
     std::string err;
     int opt_counters = 0;
     int opt_kernel = 0;
+    int opt_leaf_max = 4;
+    int opt_swizzle = 2;
     // uploaded attributes (original order)
     uint64_t n = 0;
     float *d_pos = nullptr, *d_scale = nullptr, *d_quat = nullptr, *d_opacity = nullptr, *d_sh = nullptr;

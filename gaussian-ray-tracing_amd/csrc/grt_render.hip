@@ -61,35 +61,37 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
     uint32_t cur = a.root_ref;
     while (true) {
         if (cur & kLeafBit) {
-            const uint32_t idx = cur & ~kLeafBit;
-            const float4* __restrict__ r = a.rec + (size_t)idx * 4;
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-            if (COUNT) c.proxy_tests++;
-            const f3 mu = mk3(r0.x, r0.y, r0.z);
-            m33 A;
-            A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
-            A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
-            A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-            const f3 o_g = matvec(A, sub3(o, mu));
-            const f3 d_g = matvec(A, d);
-            float te, tx;
-            if (proxy_slabs(o_g, d_g, r0.w, te, tx)) {
-                const bool in_e = (te >= t_lo) && (te < t_hi);
-                const bool in_x = (tx >= t_lo) && (tx < t_hi);
-                if (in_e || in_x) {
-                    // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357):
-                    // evaluated once, carried by the entry and the exit hit
-                    const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
-                    const uint32_t id = __float_as_uint(r2.w);
-                    if (in_e) {
-                        const uint64_t k = mk_key(te, id, 0);
-                        if (k > last_key) kbuf_insert(kb, k, alpha);
+            const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+            for (uint32_t j = 0; j < cnt; j++) {
+                const float4* __restrict__ r = a.rec + (size_t)(first + j) * 4;
+                const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                if (COUNT) c.proxy_tests++;
+                const f3 mu = mk3(r0.x, r0.y, r0.z);
+                m33 A;
+                A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+                A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+                A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+                const f3 o_g = matvec(A, sub3(o, mu));
+                const f3 d_g = matvec(A, d);
+                float te, tx;
+                if (proxy_sphere_maybe(o_g, d_g, r0.w) && proxy_slabs(o_g, d_g, r0.w, te, tx)) {
+                    const bool in_e = (te >= t_lo) && (te < t_hi);
+                    const bool in_x = (tx >= t_lo) && (tx < t_hi);
+                    if (in_e || in_x) {
+                        // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357):
+                        // evaluated once, carried by the entry and the exit hit
+                        const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
+                        const uint32_t id = __float_as_uint(r2.w);
+                        if (in_e) {
+                            const uint64_t k = mk_key(te, id, 0);
+                            if (k > last_key) kbuf_insert(kb, k, alpha);
+                        }
+                        if (in_x) {
+                            const uint64_t k = mk_key(tx, id, 1);
+                            if (k > last_key) kbuf_insert(kb, k, alpha);
+                        }
+                        if (kb.key[K - 1] != kKeyInvalid) bound = key_t(kb.key[K - 1]);
                     }
-                    if (in_x) {
-                        const uint64_t k = mk_key(tx, id, 1);
-                        if (k > last_key) kbuf_insert(kb, k, alpha);
-                    }
-                    if (kb.key[K - 1] != kKeyInvalid) bound = key_t(kb.key[K - 1]);
                 }
             }
             if (sp == 0) break;
@@ -180,16 +182,19 @@ __device__ __forceinline__ MeshHit mesh_closest(const RenderArgs& a, uint32_t* _
     uint32_t sp = 0, cur = a.mroot;
     while (true) {
         if (cur & kLeafBit) {
-            const float4* __restrict__ tr = a.tri + (size_t)(cur & ~kLeafBit) * 3;
-            const float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
-            const uint32_t face = __float_as_uint(t0.w);
-            float t, u, v;
-            if (tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, t, u, v)) {
-                const bool inside = (t > tmin) && (t < tmax);
-                const bool tie = best.hit && (t == best.t) && (face < best.face);
-                if (inside || tie) {
-                    best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
-                    tmax = t;
+            const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+            for (uint32_t j = 0; j < cnt; j++) {
+                const float4* __restrict__ tr = a.tri + (size_t)(first + j) * 3;
+                const float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
+                const uint32_t face = __float_as_uint(t0.w);
+                float t, u, v;
+                if (tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, t, u, v)) {
+                    const bool inside = (t > tmin) && (t < tmax);
+                    const bool tie = best.hit && (t == best.t) && (face < best.face);
+                    if (inside || tie) {
+                        best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
+                        tmax = t;
+                    }
                 }
             }
             if (sp == 0) break;
@@ -299,12 +304,6 @@ __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restric
 
 // workgroup -> screen block: consecutive workgroup ids go round-robin over the 8 XCDs; give each
 // XCD a contiguous run of blocks so neighbouring screen blocks share an L2 (speed only)
-__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t nb)
-{
-    const uint32_t q = nb >> 3, r = nb & 7u;
-    const uint32_t xcd = b & 7u, idx = b >> 3;
-    return xcd * q + min(xcd, r) + idx;
-}
 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     Cnt c;
-    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks);
+    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
 
@@ -387,6 +386,9 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
 {
     if (a.n_blocks == 0) return GRT_OK;
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
+    // auto: both wave kernels are bit-identical; the single-pass streaming kernel wins on large scenes (its
+    // iteration count stops growing with the scene), the round-based one on small scenes (cheaper iterations)
+    if (kernel_variant == 0 && wave_ok && a.n_prox >= 500000u) return launch_render_stream(a, count, stream, err);
     if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, stream, err);
     if (kernel_variant == 2 && !wave_ok) {
         if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";

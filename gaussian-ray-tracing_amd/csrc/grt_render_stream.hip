@@ -101,21 +101,18 @@ __device__ __forceinline__ float wave_min(float v)
 // fu0/fu1 = wave-uniform occupancy masks ----
 #define FRONTIER_PUSH(LAMBDA, REF, OK)                                                                     \
     {                                                                                                      \
-        if (~fu0) {                                                                                        \
-            const uint32_t slot_ = (uint32_t)__builtin_ctzll(~fu0);                                        \
-            fl0 = (lane == slot_) ? (LAMBDA) : fl0;                                                        \
-            fr0 = (lane == slot_) ? (REF) : fr0;                                                           \
-            fu0 |= 1ull << slot_;                                                                          \
-            OK = true;                                                                                     \
-        } else if (~fu1) {                                                                                 \
-            const uint32_t slot_ = (uint32_t)__builtin_ctzll(~fu1);                                        \
-            fl1 = (lane == slot_) ? (LAMBDA) : fl1;                                                        \
-            fr1 = (lane == slot_) ? (REF) : fr1;                                                           \
-            fu1 |= 1ull << slot_;                                                                          \
-            OK = true;                                                                                     \
-        } else {                                                                                           \
-            OK = false;                                                                                    \
-        }                                                                                                  \
+        const bool hi_ = (fu0 == ~0ull);                    /* first 64 slots full: use the second bank */ \
+        const uint64_t free_ = hi_ ? ~fu1 : ~fu0;                                                          \
+        OK = free_ != 0ull;                                                                                \
+        const uint32_t slot_ = OK ? (uint32_t)__builtin_ctzll(free_) : 64u; /* 64 matches no lane */       \
+        const bool me_ = lane == slot_;                                                                    \
+        fl0 = (me_ && !hi_) ? (LAMBDA) : fl0;                                                              \
+        fr0 = (me_ && !hi_) ? (REF) : fr0;                                                                 \
+        fl1 = (me_ && hi_) ? (LAMBDA) : fl1;                                                               \
+        fr1 = (me_ && hi_) ? (REF) : fr1;                                                                  \
+        const uint64_t bit_ = OK ? (1ull << (slot_ & 63u)) : 0ull;                                         \
+        fu0 |= hi_ ? 0ull : bit_;                                                                          \
+        fu1 |= hi_ ? bit_ : 0ull;                                                                          \
     }
 
 // depth-first overflow stack (wave-register stack: entry i = lane i of ds0 / ds1), depth <= 128
@@ -131,9 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
 {
     Cnt c;
     const uint32_t blk = [&] { // workgroup -> screen block, XCD-contiguous (speed only)
-        const uint32_t nb = a.n_blocks, b = blockIdx.x;
-        const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, idx = b >> 3;
-        return xcd * q + min(xcd, r) + idx;
+        return xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     }();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
@@ -257,41 +252,48 @@ __global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
                     const uint64_t nk = rekey ? mk_key(eo, id, 1) : kKeyInvalid;
                     SLOT_SHIFT(0, 1) SLOT_SHIFT(1, 2) SLOT_SHIFT(2, 3) SLOT_SHIFT(3, 4) SLOT_SHIFT(4, 5) SLOT_SHIFT(5, 6)
                     k6 = can_ ? kKeyInvalid : k6;
-                    uint64_t dropped_;
-                    SLOT_INSERT(nk, INFINITY, ea, dropped_) // a slot was just freed: nothing can fall off
-                    (void)dropped_;
+                    if (__any(rekey)) { // wave-uniform branch
+                        uint64_t dropped_;
+                        SLOT_INSERT(nk, INFINITY, ea, dropped_) // a slot was just freed: nothing can fall off
+                        (void)dropped_;
+                    }
                 }
                 if (final_sweep) break;
 
                 const float cut_t = (cutoff != kKeyInvalid) ? key_t(cutoff) : t_hi;
                 if (cur & kLeafBit) {
-                    const uint32_t idx = (cur & ~kLeafBit) * 4u;
-                    const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
-                                 r3 = sload4(a.rec, idx + 3);
-                    if (COUNT) { c.fetches++; if (alive) c.proxy_tests++; }
-                    const f3 mu = mk3(r0.x, r0.y, r0.z);
-                    m33 A;
-                    A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
-                    A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
-                    A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-                    const f3 o_g = matvec(A, sub3(o, mu));
-                    const f3 d_g = matvec(A, d);
-                    float te, tx;
-                    const bool hit = proxy_slabs(o_g, d_g, r0.w, te, tx) && alive;
-                    const uint32_t id = __float_as_uint(r2.w);
-                    const uint64_t ke = mk_key(te, id, 0), kx = mk_key(tx, id, 1);
-                    // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
-                    const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > pass_lo);
-                    const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
-                    const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
-                    const bool ins = (k_first != kKeyInvalid) && (k_first < cutoff);
-                    if (__any(ins)) { // wave-uniform branch
-                        // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
-                        const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
-                        const float other = (in_e && in_x) ? tx : INFINITY;
-                        uint64_t dropped;
-                        SLOT_INSERT(ins ? k_first : kKeyInvalid, other, alpha, dropped)
-                        cutoff = (dropped < cutoff) ? dropped : cutoff;
+                    const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t idx = (first + j) * 4u;
+                        const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
+                                     r3 = sload4(a.rec, idx + 3);
+                        if (COUNT) c.fetches++;
+                        const f3 mu = mk3(r0.x, r0.y, r0.z);
+                        m33 A;
+                        A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+                        A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+                        A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+                        const f3 o_g = matvec(A, sub3(o, mu));
+                        const f3 d_g = matvec(A, d);
+                        if (!__any(alive && proxy_sphere_maybe(o_g, d_g, r0.w))) continue; // no lane can touch it
+                        if (COUNT && alive) c.proxy_tests++;
+                        float te, tx;
+                        const bool hit = proxy_slabs(o_g, d_g, r0.w, te, tx) && alive;
+                        const uint32_t id = __float_as_uint(r2.w);
+                        const uint64_t ke = mk_key(te, id, 0), kx = mk_key(tx, id, 1);
+                        // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
+                        const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > pass_lo);
+                        const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
+                        const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
+                        const bool ins = (k_first != kKeyInvalid) && (k_first < cutoff);
+                        if (__any(ins)) { // wave-uniform branch
+                            // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
+                            const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
+                            const float other = (in_e && in_x) ? tx : INFINITY;
+                            uint64_t dropped;
+                            SLOT_INSERT(ins ? k_first : kKeyInvalid, other, alpha, dropped)
+                            cutoff = (dropped < cutoff) ? dropped : cutoff;
+                        }
                     }
                 } else {
                     const uint32_t idx = cur * 4u;

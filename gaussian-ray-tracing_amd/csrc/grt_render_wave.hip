@@ -90,12 +90,12 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
     while (true) {
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
         if (cur & kLeafBit) {
-            const uint32_t idx = (cur & ~kLeafBit) * 4u;
-            const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
-                         r3 = sload4(a.rec, idx + 3);
-            if (COUNT) c.fetches++;
-            {
-                if (COUNT && alive) c.proxy_tests++;
+            const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t idx = (first + j) * 4u;
+                const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
+                             r3 = sload4(a.rec, idx + 3);
+                if (COUNT) c.fetches++;
                 const f3 mu = mk3(r0.x, r0.y, r0.z);
                 m33 A;
                 A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
@@ -103,6 +103,8 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
                 A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
                 const f3 o_g = matvec(A, sub3(o, mu));
                 const f3 d_g = matvec(A, d);
+                if (!__any(alive && proxy_sphere_maybe(o_g, d_g, r0.w))) continue; // no lane can touch this proxy
+                if (COUNT && alive) c.proxy_tests++;
                 float te, tx;
                 const bool hit = proxy_slabs(o_g, d_g, r0.w, te, tx) && alive;
                 const uint32_t id = __float_as_uint(r2.w);
@@ -213,19 +215,13 @@ __device__ __forceinline__ void trace_gaussians_wave(const RenderArgs& a, bool h
     density = 1.0f - T;
 }
 
-__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t nb)
-{
-    const uint32_t q = nb >> 3, r = nb & 7u;
-    const uint32_t xcd = b & 7u, idx = b >> 3;
-    return xcd * q + min(xcd, r) + idx;
-}
 
 // no-mesh frames: raygen -> miss -> LastGaussianPass -> write (shaders/tracer.cu:17-110 with mesh_handle == 0)
 template <bool COUNT, bool SH>
 __global__ __launch_bounds__(kBlock) void k_render_wave(const RenderArgs a)
 {
     Cnt c;
-    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks);
+    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
     uint32_t px, py;
