@@ -33,6 +33,9 @@ namespace grt {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef GRT_STREAM_WAVES
+#define GRT_STREAM_WAVES 4 // waves per SIMD the register allocator must fit (128 VGPRs; a handful spill to scratch)
+#endif
 
 struct Cnt {
     uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0, fetches = 0;
@@ -124,7 +127,7 @@ __device__ __forceinline__ float wave_min(float v)
     }
 
 template <bool COUNT, bool SH>
-__global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
+__global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(const RenderArgs a)
 {
     Cnt c;
     const uint32_t blk = [&] { // workgroup -> screen block, XCD-contiguous (speed only)
@@ -223,6 +226,12 @@ __global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
                     }
                 }
                 cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                // issue the popped record's 64-B scalar fetch now: its latency overlaps the compositing below
+                const bool is_leaf = (cur & kLeafBit) != 0u;
+                const float4* pbase = is_leaf ? a.rec : a.nodes;
+                const uint32_t pidx = (is_leaf ? leaf_first(cur) : cur) * 4u;
+                const float4 p0 = sload4(pbase, pidx), p1 = sload4(pbase, pidx + 1), p2 = sload4(pbase, pidx + 2),
+                             p3 = sload4(pbase, pidx + 3);
 
                 // ---- composite every buffered event with t < F (and key < cutoff), in key order ----
                 while (true) {
@@ -261,12 +270,15 @@ __global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
                 if (final_sweep) break;
 
                 const float cut_t = (cutoff != kKeyInvalid) ? key_t(cutoff) : t_hi;
-                if (cur & kLeafBit) {
+                if (is_leaf) {
                     const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                    float4 r0 = p0, r1 = p1, r2 = p2, r3 = p3;
                     for (uint32_t j = 0; j < cnt; j++) {
-                        const uint32_t idx = (first + j) * 4u;
-                        const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
-                                     r3 = sload4(a.rec, idx + 3);
+                        if (j) {
+                            const uint32_t idx = (first + j) * 4u;
+                            r0 = sload4(a.rec, idx); r1 = sload4(a.rec, idx + 1); r2 = sload4(a.rec, idx + 2);
+                            r3 = sload4(a.rec, idx + 3);
+                        }
                         if (COUNT) c.fetches++;
                         const f3 mu = mk3(r0.x, r0.y, r0.z);
                         m33 A;
@@ -296,9 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_render_stream(const RenderArgs a)
                         }
                     }
                 } else {
-                    const uint32_t idx = cur * 4u;
-                    const float4 q0 = sload4(a.nodes, idx), q1 = sload4(a.nodes, idx + 1), q2 = sload4(a.nodes, idx + 2),
-                                 q3 = sload4(a.nodes, idx + 3);
+                    const float4 q0 = p0, q1 = p1, q2 = p2, q3 = p3;
                     if (COUNT) { c.fetches++; if (alive) c.node_visits++; }
                     float n0, f0, n1, f1;
                     box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
