@@ -39,7 +39,7 @@ def kernel_name(variant, with_mesh, n_proxies, sh_degree):
     sh = "true" if sh_degree > 0 else "false"
     if with_mesh or variant == 1:
         return "grt::k_render<false>"
-    if variant == 3 or (variant == 0 and n_proxies >= 500000):
+    if variant == 3 or (variant == 0 and n_proxies >= 250000):
         return f"grt::k_render_stream<false, {sh}>"
     return f"grt::k_render_wave<false, {sh}>"
 

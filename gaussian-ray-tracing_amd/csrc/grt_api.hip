@@ -204,6 +204,8 @@ void grt_destroy(grt_ctx* c)
     free_bvh(&c->gbvh);
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
+    (void)hipFree(c->d_sort_tmp);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -217,6 +219,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     if (!c) return GRT_ERR_INVALID;
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
+    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->cost_valid = false; }
     else if (option == GRT_OPT_SWIZZLE) {
         if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
         c->opt_swizzle = value;
@@ -318,6 +321,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     }
     (void)hipFree(d_s); (void)hipFree(d_lo); (void)hipFree(d_hi);
     c->have_timing = false;
+    c->cost_valid = false;
     if (rc == GRT_OK) c->built = true;
     return rc;
 }
@@ -420,10 +424,53 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     return GRT_OK;
 }
 
+// Frame-to-frame scheduling feedback: every render records each 16x16 block's cost (the largest number of
+// traversal iterations among its waves); the next render with the same frame geometry launches the blocks
+// heaviest-first, so the long-running tiles (10x the mean on the benchmark scenes) no longer form the tail of the
+// launch.  Pure scheduling: pixels do not depend on the order.  A viewer's consecutive frames are nearly identical,
+// which is what makes last frame's cost a good predictor; the first frame (or any change of size / mode) runs in
+// the default XCD-chunked order.
+static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s)
+{
+    a.order = nullptr;
+    a.cost = nullptr;
+    if (!c->opt_feedback || a.n_blocks == 0) return GRT_OK;
+    const uint64_t sig[6] = {a.mode, a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
+                             ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
+                             ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
+    if (c->cost_cap < a.n_blocks) {
+        (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
+        c->d_cost = c->d_order = c->d_skeys = c->d_svals = nullptr;
+        c->cost_cap = 0;
+        c->cost_valid = false;
+        CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * a.n_blocks));
+        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * a.n_blocks));
+        CHK(c, hipMalloc(&c->d_skeys, sizeof(uint32_t) * 2 * a.n_blocks));
+        CHK(c, hipMalloc(&c->d_svals, sizeof(uint32_t) * a.n_blocks));
+        c->cost_cap = a.n_blocks;
+    }
+    const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
+    if (same) {
+        int rc = sort_blocks_by_cost(c->d_cost, c->d_order, c->d_skeys, c->d_svals, &c->d_sort_tmp, &c->sort_tmp_bytes,
+                                     a.n_blocks, s, &c->err);
+        if (rc != GRT_OK) return rc;
+        a.order = c->d_order;
+    }
+    CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_blocks, s));
+    a.cost = c->d_cost;
+    memcpy(c->cost_sig, sig, sizeof(sig));
+    c->cost_valid = true;
+    return GRT_OK;
+}
+
 static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
 {
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     CHK(c, hipSetDevice(c->device));
+    {
+        int rcf = prepare_feedback(c, a, s);
+        if (rcf != GRT_OK) return rcf;
+    }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
     CHK(c, hipEventRecord(c->ev0, s));

@@ -221,6 +221,40 @@ __global__ void k_refit_pass(float4* __restrict__ nodes, uint32_t* __restrict__ 
     level[i] = pass;
 }
 
+__global__ void k_iota_neg(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ keys,
+                           uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ~cost[i]; // ascending sort of ~cost == descending cost
+    vals[i] = i;
+}
+
+int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
+                        void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err)
+{
+    if (n == 0) return GRT_OK;
+    hipLaunchKernelGGL(k_iota_neg, dim3((n + 255) / 256), dim3(256), 0, stream, d_cost, n, d_scratch_keys, d_scratch_vals);
+    size_t need = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, d_scratch_keys, d_scratch_keys + n, d_scratch_vals, d_order,
+                                             (size_t)n, 0u, 32u, stream);
+    if (e == hipSuccess && need > *tmp_bytes) {
+        if (*d_tmp) (void)hipFree(*d_tmp);
+        *d_tmp = nullptr;
+        *tmp_bytes = 0;
+        e = hipMalloc(d_tmp, need);
+        if (e == hipSuccess) *tmp_bytes = need;
+    }
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(*d_tmp, need, d_scratch_keys, d_scratch_keys + n, d_scratch_vals, d_order, (size_t)n,
+                                      0u, 32u, stream);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("sort_blocks_by_cost: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+
 void free_bvh(DevBvh* b)
 {
     if (b->nodes) (void)hipFree(b->nodes);

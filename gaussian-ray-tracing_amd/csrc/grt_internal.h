@@ -71,6 +71,8 @@ struct RenderArgs {
     uint64_t n_rays;
     uint32_t n_blocks;
     uint32_t swizzle_chunk; // see xcd_swizzle (grt_device.h); 0 = identity
+    const uint32_t* order;  // cost-sorted block order from the previous frame (heaviest first) or nullptr
+    uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
     unsigned long long* counters; // 7 x u64 or nullptr
 };
 
@@ -79,6 +81,9 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 int launch_render_stream(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 7;
+// heaviest-first block order for the next frame: order = argsort(cost, descending)
+int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
+                        void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err);
 
 }  // namespace grt
 
@@ -112,4 +117,12 @@ struct grt_ctx {
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
+    // frame-to-frame scheduling feedback (grt_api.hip: do_launch)
+    int opt_feedback = 1;
+    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_skeys = nullptr, *d_svals = nullptr;
+    void* d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t cost_cap = 0;
+    bool cost_valid = false;
+    uint64_t cost_sig[6] = {0, 0, 0, 0, 0, 0};
 };

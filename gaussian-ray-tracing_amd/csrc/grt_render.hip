@@ -20,7 +20,7 @@ constexpr int K = 7;           // MaxNumHitPerTrace, shaders/tracer.cuh:11
 constexpr int kBlock = 256;
 
 struct Cnt {
-    uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0;
+    uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0, iters = 0;
 };
 
 struct KBuf {
@@ -60,6 +60,7 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
     uint32_t sp = 0;
     uint32_t cur = a.root_ref;
     while (true) {
+        c.iters++;
         if (cur & kLeafBit) {
             const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
             for (uint32_t j = 0; j < cnt; j++) {
@@ -181,6 +182,7 @@ __device__ __forceinline__ MeshHit mesh_closest(const RenderArgs& a, uint32_t* _
     const rayinv ri = mk_rayinv(o, d);
     uint32_t sp = 0, cur = a.mroot;
     while (true) {
+        c.iters++;
         if (cur & kLeafBit) {
             const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
             for (uint32_t j = 0; j < cnt; j++) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     Cnt c;
-    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
+    const uint32_t blk = a.order ? a.order[blockIdx.x] : xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
 
@@ -369,6 +371,11 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
         }
     }
 
+    if (a.cost) { // scheduling feedback: the block's cost is its slowest lane
+        uint32_t m = c.iters;
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if (lane == 0) atomicMax(&a.cost[blk], m);
+    }
     if (COUNT) {
         uint32_t v[6] = {c.rays, c.segments, c.hit_evals, c.rounds, c.node_visits, c.proxy_tests};
 #pragma unroll
@@ -388,7 +395,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
     // auto: both wave kernels are bit-identical; the single-pass streaming kernel wins on large scenes (its
     // iteration count stops growing with the scene), the round-based one on small scenes (cheaper iterations)
-    if (kernel_variant == 0 && wave_ok && a.n_prox >= 500000u) return launch_render_stream(a, count, stream, err);
+    if (kernel_variant == 0 && wave_ok && a.n_prox >= 250000u) return launch_render_stream(a, count, stream, err);
     if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, stream, err);
     if (kernel_variant == 2 && !wave_ok) {
         if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
 {
     Cnt c;
     const uint32_t blk = [&] { // workgroup -> screen block, XCD-contiguous (speed only)
-        return xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
+        return a.order ? a.order[blockIdx.x] : xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     }();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
         bool alive = have_ray && (T > minT);
         uint32_t stalls = 0;
         SLOT_DECL
+        uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
         while (__any(alive)) { // one iteration = one front-to-back pass
             if (COUNT && alive) c.rounds++;
             const uint64_t pass_lo = last_key; // events with key <= pass_lo were composited by an earlier pass
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                     }
                 }
                 cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                ++iters;
                 // issue the popped record's 64-B scalar fetch now: its latency overlaps the compositing below
                 const bool is_leaf = (cur & kLeafBit) != 0u;
                 const float4* pbase = is_leaf ? a.rec : a.nodes;
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
             stalls = progressed ? 0u : stalls + 1u;
             alive = alive && (cutoff != kKeyInvalid) && (stalls < 2u);
         }
+        if (a.cost && lane == 0) atomicMax(&a.cost[blk], iters);
     }
     const float density = 1.0f - T;
 

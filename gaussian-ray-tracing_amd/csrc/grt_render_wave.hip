@@ -28,7 +28,7 @@ constexpr int K = 7; // MaxNumHitPerTrace, shaders/tracer.cuh:11
 constexpr int kBlock = 256;
 
 struct Cnt {
-    uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0, fetches = 0;
+    uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0, fetches = 0, iters = 0;
 };
 
 struct KBuf {
@@ -89,6 +89,7 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
     uint32_t cur = a.root_ref;
     while (true) {
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        c.iters++;
         if (cur & kLeafBit) {
             const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
             for (uint32_t j = 0; j < cnt; j++) {
@@ -221,7 +222,7 @@ template <bool COUNT, bool SH>
 __global__ __launch_bounds__(kBlock) void k_render_wave(const RenderArgs a)
 {
     Cnt c;
-    const uint32_t blk = xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
+    const uint32_t blk = a.order ? a.order[blockIdx.x] : xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
     uint32_t px, py;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_render_wave(const RenderArgs a)
             a.out8[out_idx * 3 + 2] = quantize8(col.z);
         }
     }
+    if (a.cost && lane == 0) atomicMax(&a.cost[blk], c.iters);
     if (COUNT) {
         // fetches are wave-level events: count them once per wave
         uint32_t v[7] = {c.rays, c.segments, c.hit_evals, c.rounds, c.node_visits, c.proxy_tests, 0};

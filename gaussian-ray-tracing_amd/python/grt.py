@@ -49,7 +49,7 @@ class Mesh(C.Structure):
 
 
 MIRROR, NORMAL, GLASS = 0, 1, 2
-OPT_COUNTERS, OPT_KERNEL, OPT_LEAF_MAX, OPT_SWIZZLE = 1, 2, 3, 4
+OPT_COUNTERS, OPT_KERNEL, OPT_LEAF_MAX, OPT_SWIZZLE, OPT_FEEDBACK = 1, 2, 3, 4, 5
 
 EXPORTS = [
     "grt_create", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
