@@ -198,10 +198,14 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
             }
             float F = 0.0f;
             bool final_sweep = false;
+            uint32_t bypass = kNoRoot; // a child whose key equals F is a frontier minimum: expand it next, no push/pop
             while (true) {
                 uint32_t cur = 0;
                 if (!final_sweep) {
-                    if (!__any(alive) || (dsp == 0 && !(fu0 | fu1))) {
+                    if (bypass != kNoRoot && __any(alive)) {
+                        cur = bypass;
+                        bypass = kNoRoot;
+                    } else if (!__any(alive) || (dsp == 0 && !(fu0 | fu1))) {
                         // frontier exhausted (or every lane done): everything still buffered is final
                         F = INFINITY;
                         final_sweep = true;
@@ -321,20 +325,26 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                     const bool h1 = alive && (n1 <= f1) && (f1 >= lo) && (n1 <= cut_t) && (n1 < t_hi);
                     const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
                     const bool any0 = __any(h0), any1 = __any(h1);
+                    // both reductions back to back (independent chains overlap)
+                    const float lam0 = wave_min(h0 ? fmaxf(n0, 0.0f) : INFINITY);
+                    const float lam1 = wave_min(h1 ? fmaxf(n1, 0.0f) : INFINITY);
                     if (dsp) { // already depth-first below a full frontier: stay depth-first
                         if (any1) DFS_PUSH(c1)
                         if (any0) DFS_PUSH(c0)
                     } else {
-                        if (any0) {
-                            const float lam = wave_min(h0 ? fmaxf(n0, 0.0f) : INFINITY);
+                        // a child whose key equals the bound F just popped is a minimum of the frontier (every entry
+                        // is >= F): expand it right away instead of pushing and popping it
+                        const bool by0 = any0 && (lam0 <= F);
+                        const bool by1 = any1 && !by0 && (lam1 <= F);
+                        bypass = by0 ? c0 : (by1 ? c1 : kNoRoot);
+                        if (any0 && !by0) {
                             bool ok;
-                            FRONTIER_PUSH(lam, c0, ok)
+                            FRONTIER_PUSH(lam0, c0, ok)
                             if (!ok) DFS_PUSH(c0)
                         }
-                        if (any1) {
-                            const float lam = wave_min(h1 ? fmaxf(n1, 0.0f) : INFINITY);
+                        if (any1 && !by1) {
                             bool ok = false;
-                            if (!dsp) FRONTIER_PUSH(lam, c1, ok)
+                            if (!dsp) FRONTIER_PUSH(lam1, c1, ok)
                             if (!ok) DFS_PUSH(c1)
                         }
                     }
