@@ -206,6 +206,7 @@ void grt_destroy(grt_ctx* c)
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
     (void)hipFree(c->d_sort_tmp);
+    (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -473,6 +474,20 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
+    a.prec = nullptr; a.queue = nullptr; a.qcount = nullptr;
+    if (c->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
+        const size_t need = (size_t)a.n_blocks * 256;
+        if (c->wf_cap < need) {
+            (void)hipFree(c->d_prec); (void)hipFree(c->d_queue);
+            c->d_prec = c->d_queue = nullptr;
+            c->wf_cap = 0;
+            CHK(c, hipMalloc(&c->d_prec, need * 3 * sizeof(float4)));
+            CHK(c, hipMalloc(&c->d_queue, need * 4 * sizeof(float4)));
+            c->wf_cap = need;
+        }
+        if (!c->d_qcount) CHK(c, hipMalloc(&c->d_qcount, sizeof(uint32_t)));
+        a.prec = c->d_prec; a.queue = c->d_queue; a.qcount = c->d_qcount;
+    }
     CHK(c, hipEventRecord(c->ev0, s));
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));

@@ -74,12 +74,16 @@ struct RenderArgs {
     const uint32_t* order;  // cost-sorted block order from the previous frame (heaviest first) or nullptr
     uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
     unsigned long long* counters; // 7 x u64 or nullptr
+    // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
+    float4* prec;      // [n_blocks*256][3] primary mesh-hit records
+    float4* queue;     // [n_blocks*256][4] compacted continuation rays
+    uint32_t* qcount;  // number of queued rays
 };
 
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
                   std::string* err);
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
-int launch_render_stream(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
+int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 7;
 // heaviest-first block order for the next frame: order = argsort(cost, descending)
 int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
@@ -124,5 +128,9 @@ struct grt_ctx {
     size_t sort_tmp_bytes = 0;
     uint32_t cost_cap = 0;
     bool cost_valid = false;
+    // wavefront buffers (allocated on first mesh frame)
+    float4 *d_prec = nullptr, *d_queue = nullptr;
+    uint32_t* d_qcount = nullptr;
+    size_t wf_cap = 0;
     uint64_t cost_sig[6] = {0, 0, 0, 0, 0, 0};
 };

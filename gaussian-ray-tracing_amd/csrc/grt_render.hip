@@ -239,44 +239,63 @@ __device__ __forceinline__ f3 bary_normal(const RenderArgs& a, const MeshHit& h)
     return normalize3(add3(add3(mul3s(n0, w0), mul3s(n1, w1)), mul3s(n2, w2)));
 }
 
-// __raygen__raygeneration bounce loop + __closesthit__ + __miss__ (shaders/tracer.cu:58-106,112-122,155-187)
-template <bool COUNT>
-__device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, f3 curO, f3 curD, Cnt& c)
+enum { LastGaussianPass = 0, GaussianPass = 1, MeshPass = 2, Terminate = 3 }; // src/Parameters.h:85-91
+
+// RayPayload + RayData (shaders/tracer.cuh:24-56) as far as the bounce loop carries them
+struct RayState {
+    f3 curO, curD, accumColor;
+    float accumAlpha, blocking, density;
+    uint32_t numBounces, timeout;
+};
+
+// __closesthit__closesthit / __miss__miss for one mesh trace (shaders/tracer.cu:112-122,155-187): decides the state,
+// the upper end of this iteration's Gaussian segment and the next ray
+__device__ __forceinline__ void mesh_shade(const RenderArgs& a, const MeshHit& mh, f3 ray_o, f3 ray_d, int& state,
+                                           float& seg_tmax, f3& normal, f3& curO, f3& curD, uint32_t& numBounces)
 {
-    enum { LastGaussianPass = 0, GaussianPass = 1, MeshPass = 2, Terminate = 3 }; // src/Parameters.h:85-91
-    f3 accumColor = mk3(0, 0, 0), directLight = mk3(0, 0, 0);
-    float accumAlpha = 0.0f, blocking = 0.0f, density = 0.0f;
-    uint32_t numBounces = 0, timeout = 0;
+    normal = mk3(0, 0, 0);
+    seg_tmax = a.p.t_max; // LastGaussianPass traces to t_max (shaders/tracer.cu:70-75)
+    if (mh.hit) {
+        float t_hit = mh.t;
+        normal = bary_normal(a, mh);
+        f3 newDir = mk3(0, 0, 0);
+        state = GaussianPass;
+        seg_tmax = t_hit;
+        if (a.p.type == GRT_MIRROR) { // renderMirror, shaders/tracer.cuh:396-404
+            newDir = reflect3(ray_d, normal);
+            numBounces += 1;
+        } else if (a.p.type == GRT_NORMAL) { // renderNormal traces [t_min, t_hit] itself, shaders/tracer.cuh:406-429
+            state = Terminate;
+        } else if (a.p.type == GRT_GLASS) { // renderGlass, shaders/tracer.cuh:466-482
+            const float n1 = 1.0003f, n2 = 1.5f;
+            if (refract_dir(ray_d, normal, n2 / n1, newDir)) t_hit += kRefractionEpsShift;
+            else numBounces += 1;
+            seg_tmax = t_hit; // payload.t_hit carries the shifted value (shaders/tracer.cu:180)
+        }
+        curO = add3(ray_o, mul3s(ray_d, t_hit));
+        curD = newDir;
+    } else { // __miss__miss
+        curO = mk3(0, 0, 0);
+        curD = mk3(0, 0, 0);
+        state = LastGaussianPass;
+    }
+}
+
+// __raygen__raygeneration bounce loop (shaders/tracer.cu:58-106), resumable from a RayState
+template <bool COUNT>
+__device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, RayState st, Cnt& c)
+{
+    f3 curO = st.curO, curD = st.curD;
+    f3 accumColor = st.accumColor, directLight = mk3(0, 0, 0);
+    float accumAlpha = st.accumAlpha, blocking = st.blocking, density = st.density;
+    uint32_t numBounces = st.numBounces, timeout = st.timeout;
     while (length3(curD) > 0.1f && numBounces < a.p.max_bounces) {
         const f3 ray_o = curO, ray_d = curD;
         int state = MeshPass;
         const MeshHit mh = mesh_closest<COUNT>(a, stk, ray_o, ray_d, kTraceMeshTmin, kTraceMeshTmax, c);
-        f3 normal = mk3(0, 0, 0);
-        float seg_tmax = a.p.t_max; // LastGaussianPass traces to t_max (shaders/tracer.cu:70-75)
-        if (mh.hit) {
-            float t_hit = mh.t;
-            normal = bary_normal(a, mh);
-            f3 newDir = mk3(0, 0, 0);
-            state = GaussianPass;
-            seg_tmax = t_hit;
-            if (a.p.type == GRT_MIRROR) { // renderMirror, shaders/tracer.cuh:396-404
-                newDir = reflect3(ray_d, normal);
-                numBounces += 1;
-            } else if (a.p.type == GRT_NORMAL) { // renderNormal traces [t_min, t_hit] itself, shaders/tracer.cuh:406-429
-                state = Terminate;
-            } else if (a.p.type == GRT_GLASS) { // renderGlass, shaders/tracer.cuh:466-482
-                const float n1 = 1.0003f, n2 = 1.5f;
-                if (refract_dir(ray_d, normal, n2 / n1, newDir)) t_hit += kRefractionEpsShift;
-                else numBounces += 1;
-                seg_tmax = t_hit; // payload.t_hit carries the shifted value (shaders/tracer.cu:180)
-            }
-            curO = add3(ray_o, mul3s(ray_d, t_hit));
-            curD = newDir;
-        } else { // __miss__miss
-            curO = mk3(0, 0, 0);
-            curD = mk3(0, 0, 0);
-            state = LastGaussianPass;
-        }
+        f3 normal;
+        float seg_tmax;
+        mesh_shade(a, mh, ray_o, ray_d, state, seg_tmax, normal, curO, curD, numBounces);
         // the single Gaussian segment of this iteration (one call site keeps the kernel small)
         f3 rad;
         trace_gaussians<COUNT>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c);
@@ -307,6 +326,126 @@ __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restric
 // workgroup -> screen block: consecutive workgroup ids go round-robin over the 8 XCDs; give each
 // XCD a contiguous run of blocks so neighbouring screen blocks share an L2 (speed only)
 
+__device__ __forceinline__ RayState fresh_ray(f3 o, f3 d)
+{
+    RayState st;
+    st.curO = o; st.curD = d; st.accumColor = mk3(0, 0, 0);
+    st.accumAlpha = 0.0f; st.blocking = 0.0f; st.density = 0.0f;
+    st.numBounces = 0; st.timeout = 0;
+    return st;
+}
+
+// ---- wavefront pipeline for mesh frames -------------------------------------------------------------------
+// stage 1 (this kernel): camera ray + mesh closest hit + closest-hit shading for every pixel, one record per thread
+//   prec[3*i+0] = (seg_tmax, flags, curO.x, curO.y)   flags = state | numBounces << 8 | have_ray << 16
+//   prec[3*i+1] = (curO.z, curD.x, curD.y, curD.z)     prec[3*i+2] = (normal.xyz, 0)
+// stage 2 (grt_render_stream.hip, MESH = true): the coherent primary Gaussian segment [t_min, seg_tmax] on the
+//   wave-cooperative streaming kernel, first iteration of the compositing, and COMPACTION of the rays that go
+//   on (wave ballot + popcount prefix + one atomicAdd per wave) into the continuation queue
+// stage 3 (k_bounce): the queued, now incoherent, rays finish their bounce loop on the per-lane traversal
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_primary_mesh(const RenderArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    Cnt c;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    uint32_t px, py;
+    bool in_frame;
+    if (a.mode == 0) {
+        px = a.x0 + (blk % a.nbx) * 16u + lx;
+        py = a.y0 + (blk / a.nbx) * 16u + ly;
+        in_frame = (px < a.x1) && (py < a.y1);
+    } else {
+        const uint32_t per_tile = a.nbx * a.nby;
+        const uint32_t j = blk / per_tile, sub = blk % per_tile;
+        const uint32_t tile = a.first_tile + j * a.tile_stride;
+        px = (tile % a.tiles_x) * a.tile_w + (sub % a.nbx) * 16u + lx;
+        py = (tile / a.tiles_x) * a.tile_h + (sub / a.nbx) * 16u + ly;
+        in_frame = (px < a.p.width) && (py < a.p.height);
+    }
+    const f3 nU = mk3(-a.p.U[0], -a.p.U[1], -a.p.U[2]), nV = mk3(-a.p.V[0], -a.p.V[1], -a.p.V[2]);
+    const f3 W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
+    const f3 eye = mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]);
+    f3 dir = mk3(0, 0, 0);
+    bool have_ray = in_frame;
+    if (in_frame) {
+        if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+        else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+    }
+    if (COUNT && have_ray) c.rays++;
+    have_ray = have_ray && (length3(dir) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
+    int state = MeshPass;
+    float seg_tmax = a.p.t_max;
+    f3 normal = mk3(0, 0, 0), curO = mk3(0, 0, 0), curD = mk3(0, 0, 0);
+    uint32_t numBounces = 0;
+    if (have_ray) {
+        const MeshHit mh = mesh_closest<COUNT>(a, stk, eye, dir, kTraceMeshTmin, kTraceMeshTmax, c);
+        mesh_shade(a, mh, eye, dir, state, seg_tmax, normal, curO, curD, numBounces);
+    }
+    const size_t i = ((size_t)blk * kBlock + threadIdx.x) * 3;
+    const uint32_t flags = (uint32_t)state | (numBounces << 8) | ((have_ray ? 1u : 0u) << 16);
+    a.prec[i + 0] = make_float4(seg_tmax, __uint_as_float(flags), curO.x, curO.y);
+    a.prec[i + 1] = make_float4(curO.z, curD.x, curD.y, curD.z);
+    a.prec[i + 2] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    if (COUNT) {
+        uint32_t v[2] = {c.rays, c.node_visits};
+        for (int k = 0; k < 2; k++) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+            if (lane == 0 && x) {
+                atomicAdd(&a.counters[k == 0 ? 0 : 4], (unsigned long long)x);
+                if (k == 1) atomicAdd(&a.counters[6], (unsigned long long)x);
+            }
+        }
+    }
+}
+
+// stage 3: finish the queued rays (queue record layout: see grt_render_stream.hip, enqueue)
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    Cnt c;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = *a.qcount;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (blockIdx.x * kBlock >= n) return;
+    if (i < n) {
+        const float4 q0 = a.queue[(size_t)i * 4], q1 = a.queue[(size_t)i * 4 + 1], q2 = a.queue[(size_t)i * 4 + 2],
+                     q3 = a.queue[(size_t)i * 4 + 3];
+        RayState st;
+        st.curO = mk3(q0.x, q0.y, q0.z);
+        st.curD = mk3(q0.w, q1.x, q1.y);
+        st.accumColor = mk3(q1.z, q1.w, q2.x);
+        st.accumAlpha = q2.y; st.blocking = q2.z; st.density = q2.w;
+        st.numBounces = __float_as_uint(q3.x); st.timeout = __float_as_uint(q3.y);
+        const size_t out_idx = (size_t)__float_as_uint(q3.z) | ((size_t)__float_as_uint(q3.w) << 32);
+        const f3 col = shade_ray<COUNT>(a, stk, st, c);
+        if (a.outf) {
+            a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
+        }
+        if (a.out8) {
+            a.out8[out_idx * 3] = quantize8(col.x);
+            a.out8[out_idx * 3 + 1] = quantize8(col.y);
+            a.out8[out_idx * 3 + 2] = quantize8(col.z);
+        }
+    }
+    if (COUNT) {
+        uint32_t v[6] = {0u, c.segments, c.hit_evals, c.rounds, c.node_visits, c.proxy_tests};
+#pragma unroll
+        for (int k = 1; k < 6; k++) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+            if (lane == 0 && x) atomicAdd(&a.counters[k], (unsigned long long)x);
+            if (lane == 0 && x && k >= 4) atomicAdd(&a.counters[6], (unsigned long long)x);
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
 {
@@ -322,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
         if (i < a.n_rays) {
             const float* r = a.rays + i * 6;
             if (COUNT) c.rays++;
-            const f3 col = shade_ray<COUNT>(a, stk, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), c);
+            const f3 col = shade_ray<COUNT>(a, stk, fresh_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])), c);
             a.outf[i * 3] = col.x; a.outf[i * 3 + 1] = col.y; a.outf[i * 3 + 2] = col.z;
         }
     } else {
@@ -356,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
             else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
             if (have_ray) {
                 if (COUNT) c.rays++;
-                col = shade_ray<COUNT>(a, stk, mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]), dir, c);
+                col = shade_ray<COUNT>(a, stk, fresh_ray(mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]), dir), c);
             }
         }
         if (write) {
@@ -392,17 +531,46 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
                   std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
+    const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
     // auto: both wave kernels are bit-identical; the single-pass streaming kernel wins on large scenes (its
     // iteration count stops growing with the scene), the round-based one on small scenes (cheaper iterations)
-    if (kernel_variant == 0 && wave_ok && a.n_prox >= 250000u) return launch_render_stream(a, count, stream, err);
-    if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, stream, err);
+    if (kernel_variant == 0 && wave_ok && a.n_prox >= 250000u) return launch_render_stream(a, count, false, stream, err);
+    if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, false, stream, err);
+    // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
+    if (kernel_variant != 1 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
+        if (lds > 160 * 1024) {
+            if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
+            return GRT_ERR_LIMIT;
+        }
+        hipError_t e = hipMemsetAsync(a.qcount, 0, sizeof(uint32_t), stream);
+        auto fp = count ? k_primary_mesh<true> : k_primary_mesh<false>;
+        auto fb = count ? k_bounce<true> : k_bounce<false>;
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            if (err) *err = std::string("wavefront setup: ") + hipGetErrorString(e);
+            return GRT_ERR_HIP;
+        }
+        hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
+        int rc = launch_render_stream(a, count, true, stream, err);
+        if (rc != GRT_OK) return rc;
+        RenderArgs b = a;
+        b.order = nullptr;
+        b.cost = nullptr;
+        hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            if (err) *err = std::string("wavefront launch: ") + hipGetErrorString(e);
+            return GRT_ERR_HIP;
+        }
+        return GRT_OK;
+    }
     if (kernel_variant == 2 && !wave_ok) {
         if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";
         return GRT_ERR_INVALID;
     }
     if (kernel_variant != 1 && kernel_variant != 3 && wave_ok) return launch_render_wave(a, count, stream, err);
-    const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     if (lds > 160 * 1024) {
         if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
         return GRT_ERR_LIMIT;

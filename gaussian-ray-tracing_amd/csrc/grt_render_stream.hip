@@ -126,7 +126,7 @@ __device__ __forceinline__ float wave_min(float v)
         ++dsp;                                                                                             \
     }
 
-template <bool COUNT, bool SH>
+template <bool COUNT, bool SH, bool MESH>
 __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(const RenderArgs a)
 {
     Cnt c;
@@ -164,8 +164,22 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
         if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
         else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
     }
-    if (COUNT && have_ray) c.rays++;
+    if (COUNT && have_ray && !MESH) c.rays++;
     have_ray = have_ray && (length3(d) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
+    // MESH: stage 1 (k_primary_mesh) already traced the mesh for this pixel
+    float seg_tmax = a.p.t_max;
+    uint32_t pflags = 0;
+    f3 nextO = mk3(0, 0, 0), nextD = mk3(0, 0, 0), hitN = mk3(0, 0, 0);
+    if (MESH) {
+        const size_t pi = ((size_t)blk * kBlock + threadIdx.x) * 3;
+        const float4 pr0 = a.prec[pi], pr1 = a.prec[pi + 1], pr2 = a.prec[pi + 2];
+        seg_tmax = pr0.x;
+        pflags = __float_as_uint(pr0.y);
+        nextO = mk3(pr0.z, pr0.w, pr1.x);
+        nextD = mk3(pr1.y, pr1.z, pr1.w);
+        hitN = mk3(pr2.x, pr2.y, pr2.z);
+        have_ray = have_ray && ((pflags >> 16) & 1u);
+    }
 
     // ---- trace() for the whole wave (shaders/tracer.cuh:328-373), density starts at 0 ----
     const float minT = a.p.minTransmittance;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
         const float epsT = 1e-9f;
         const f3 dn = normalize3(d);
         const rayinv ri = mk_rayinv(o, d);
-        const float t_hi = a.p.t_max + epsT;
+        const float t_hi = seg_tmax + epsT; // per lane when MESH (segment ends at the mesh hit)
         uint64_t last_key = mk_key(a.p.t_min + epsT, 0x7FFFFFFFu, 1); // last composited event (exclusive bound)
         bool alive = have_ray && (T > minT);
         uint32_t stalls = 0;
@@ -360,12 +374,59 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
     const float density = 1.0f - T;
 
     f3 col = mk3(0.0f, 0.0f, 0.0f);
+    bool cont = false; // MESH: the ray goes on bouncing (stage 3)
+    f3 accumColor = mk3(0, 0, 0);
+    float accumAlpha = 0.0f, blocking = 0.0f;
+    const uint32_t numBounces = (pflags >> 8) & 0xFFu;
     if (have_ray) {
         const float alpha = density;
-        const f3 directLight = mul3s(radiance, alpha);     // shaders/tracer.cu:80
-        col = add3(col, mul3s(directLight, 1.0f - 0.0f));  // shaders/tracer.cu:101 with blocking == 0
+        if (!MESH) {
+            const f3 directLight = mul3s(radiance, alpha);     // shaders/tracer.cu:80
+            col = add3(col, mul3s(directLight, 1.0f - 0.0f));  // shaders/tracer.cu:101 with blocking == 0
+        } else {
+            // first iteration of the bounce loop (shaders/tracer.cu:58-106) with all accumulators at zero
+            const uint32_t state = pflags & 0xFFu;
+            f3 directLight = mk3(0, 0, 0);
+            if (state == 3u) { // Terminate: renderNormal, shaders/tracer.cuh:417-428
+                accumColor = add3(accumColor, radiance);
+                accumAlpha += alpha;
+                const f3 normalColor = mul3s(add3(hitN, mk3(1.0f, 1.0f, 1.0f)), 0.5f);
+                accumColor = add3(accumColor, mul3s(normalColor, 1.0f - alpha));
+            } else {
+                if (state == 0u) { // LastGaussianPass, shaders/tracer.cu:68-82
+                    directLight = mul3s(radiance, alpha);
+                    accumAlpha = clampf(accumAlpha + alpha, 0.0f, 1.0f);
+                } else {           // shaders/tracer.cu:84-98
+                    accumColor = add3(accumColor, mul3s(radiance, 1.0f - accumAlpha));
+                    accumAlpha = clampf(accumAlpha + alpha, 0.0f, 1.0f);
+                    blocking = clampf(blocking + alpha, 0.0f, 1.0f);
+                }
+                accumColor = add3(accumColor, mul3s(directLight, 1.0f - blocking)); // shaders/tracer.cu:101
+                cont = (length3(nextD) > 0.1f) && (numBounces < a.p.max_bounces);
+            }
+            col = accumColor;
+        }
     }
-    if (write) {
+    if (MESH) {
+        // ---- compaction of the rays that go on: wave ballot + popcount prefix + ONE atomic per wave ----
+        const uint64_t mask = __ballot(cont);
+        if (mask) { // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.qcount, (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (cont) {
+                const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                float4* q = a.queue + (size_t)slot * 4;
+                q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
+                q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);
+                q[2] = make_float4(accumColor.z, accumAlpha, blocking, density);
+                q[3] = make_float4(__uint_as_float(numBounces), __uint_as_float(1u), // timeout after one iteration
+                                   __uint_as_float((uint32_t)out_idx), __uint_as_float((uint32_t)(out_idx >> 32)));
+            }
+        }
+    }
+    const bool write_px = write && !cont; // queued rays write their pixel in stage 3
+    if (write_px) {
         if (a.outf) {
             a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
         }
@@ -396,12 +457,17 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
 
 } // namespace
 
-int launch_render_stream(const RenderArgs& a, bool count, hipStream_t stream, std::string* err)
+int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
     const bool sh = a.p.sh_degree_max > 0;
-    auto fn = count ? (sh ? k_render_stream<true, true> : k_render_stream<true, false>)
-                    : (sh ? k_render_stream<false, true> : k_render_stream<false, false>);
+    void (*fn)(const RenderArgs);
+    if (!mesh)
+        fn = count ? (sh ? k_render_stream<true, true, false> : k_render_stream<true, false, false>)
+                   : (sh ? k_render_stream<false, true, false> : k_render_stream<false, false, false>);
+    else
+        fn = count ? (sh ? k_render_stream<true, true, true> : k_render_stream<true, false, true>)
+                   : (sh ? k_render_stream<false, true, true> : k_render_stream<false, false, true>);
     hipLaunchKernelGGL(fn, dim3(a.n_blocks), dim3(kBlock), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
