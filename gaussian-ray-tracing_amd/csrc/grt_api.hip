@@ -242,7 +242,7 @@ int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
         if (c) c->err = "grt_upload_gaussians: null argument";
         return GRT_ERR_INVALID;
     }
-    if (n >= 0x7FFFFFFFull) { c->err = "grt_upload_gaussians: more than 2^31-1 particles"; return GRT_ERR_LIMIT; }
+    if (n >= (1ull << 27)) { c->err = "grt_upload_gaussians: more than 2^27-1 particles (hit keys carry a 27-bit id)"; return GRT_ERR_LIMIT; }
     CHK(c, hipSetDevice(c->device));
     CHK(c, hipStreamSynchronize(c->stream));
     free_gaussians(c);

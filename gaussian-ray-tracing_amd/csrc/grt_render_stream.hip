@@ -70,35 +70,43 @@ __device__ __forceinline__ float wave_min(float v)
 #endif
 }
 
-// ---- per-lane particle slots: k0..k6 (current key, ascending; ~0 = free), o0..o6 (exit t while the key is
-// the entry event; +inf = no exit event), a0..a6 (alpha) ----
+// ---- per-lane particle slots.  Registers hold only the 12 sorted 64-bit keys k0..k11 (~0 = free); each key
+// carries, in its 4 lowest bits, the index of its payload cell in LDS (exit t while the key is the entry event —
+// +inf = no exit event — and alpha), so sorting moves 2 registers per slot and the window is 12 particles
+// (~24 hits) for fewer registers than 7 register-resident (key, other, alpha) slots.
+//   key = t bits << 32 | particle id << 5 | exit << 4 | payload cell          (particle ids < 2^27)
+constexpr int KS = 12;
+constexpr uint64_t kCellMask = 15ull;
+__device__ __forceinline__ uint64_t mk_skey(float t, uint32_t id, uint32_t is_exit)
+{
+    return ((uint64_t)__float_as_uint(t) << 32) | (uint64_t)((id << 5) | (is_exit << 4));
+}
+__device__ __forceinline__ uint32_t skey_id(uint64_t k) { return ((uint32_t)k) >> 5; }
 #define SLOT_DECL                                                                                          \
     uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,   \
-             k5 = kKeyInvalid, k6 = kKeyInvalid;                                                           \
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, o4 = 0.f, o5 = 0.f, o6 = 0.f;                         \
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f;
-#define SLOT_CLEAR k0 = k1 = k2 = k3 = k4 = k5 = k6 = kKeyInvalid;
+             k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid, k8 = kKeyInvalid, k9 = kKeyInvalid,   \
+             k10 = kKeyInvalid, k11 = kKeyInvalid;                                                         \
+    uint32_t pmask = 0; /* payload cells in use */
+#define SLOT_CLEAR                                                                                         \
+    k0 = k1 = k2 = k3 = k4 = k5 = k6 = k7 = k8 = k9 = k10 = k11 = kKeyInvalid;                            \
+    pmask = 0;
 #define SLOT_STEP(i)                                                                                       \
     {                                                                                                      \
         const bool lt_ = ik_ < k##i;                                                                       \
         const uint64_t tk_ = k##i;                                                                         \
-        const float to_ = o##i, ta_ = a##i;                                                                \
         k##i = lt_ ? ik_ : tk_;                                                                            \
-        o##i = lt_ ? io_ : to_;                                                                            \
-        a##i = lt_ ? ia_ : ta_;                                                                            \
         ik_ = lt_ ? tk_ : ik_;                                                                             \
-        io_ = lt_ ? to_ : io_;                                                                             \
-        ia_ = lt_ ? ta_ : ia_;                                                                             \
     }
-// branch-free sorted insert of (KEY, OTHER, ALPHA); KEY == ~0 is a no-op; DROPPED receives what fell off the end
-#define SLOT_INSERT(KEY, OTHER, ALPHA, DROPPED)                                                            \
+// branch-free sorted insert of KEY (with its cell bits); KEY == ~0 is a no-op.  The caller guarantees room.
+#define SLOT_INSERT(KEY)                                                                                   \
     {                                                                                                      \
         uint64_t ik_ = (KEY);                                                                              \
-        float io_ = (OTHER), ia_ = (ALPHA);                                                                \
         SLOT_STEP(0) SLOT_STEP(1) SLOT_STEP(2) SLOT_STEP(3) SLOT_STEP(4) SLOT_STEP(5) SLOT_STEP(6)         \
-        DROPPED = ik_;                                                                                     \
+        SLOT_STEP(7) SLOT_STEP(8) SLOT_STEP(9) SLOT_STEP(10) SLOT_STEP(11)                                 \
     }
-#define SLOT_SHIFT(i, j) { k##i = can_ ? k##j : k##i; o##i = can_ ? o##j : o##i; a##i = can_ ? a##j : a##i; }
+#define SLOT_SHIFT(i, j) { k##i = can_ ? k##j : k##i; }
+#define PL_OTHER(cell) pl_other[(cell) * kBlock + threadIdx.x]
+#define PL_ALPHA(cell) pl_alpha[(cell) * kBlock + threadIdx.x]
 
 // ---- wave-level frontier: slot i (0..63) = lane i of (fl0, fr0), slot 64+i = lane i of (fl1, fr1);
 // fu0/fu1 = wave-uniform occupancy masks ----
@@ -129,6 +137,7 @@ __device__ __forceinline__ float wave_min(float v)
 template <bool COUNT, bool SH, bool MESH>
 __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(const RenderArgs a)
 {
+    __shared__ float pl_other[KS * kBlock], pl_alpha[KS * kBlock];
     Cnt c;
     const uint32_t blk = [&] { // workgroup -> screen block, XCD-contiguous (speed only)
         return a.order ? a.order[blockIdx.x] : xcd_swizzle(blockIdx.x, a.n_blocks, a.swizzle_chunk);
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
         const f3 dn = normalize3(d);
         const rayinv ri = mk_rayinv(o, d);
         const float t_hi = seg_tmax + epsT; // per lane when MESH (segment ends at the mesh hit)
-        uint64_t last_key = mk_key(a.p.t_min + epsT, 0x7FFFFFFFu, 1); // last composited event (exclusive bound)
+        uint64_t last_key = mk_skey(a.p.t_min + epsT, 0x07FFFFFFu, 1) | kCellMask; // last composited event (exclusive bound)
         bool alive = have_ray && (T > minT);
         uint32_t stalls = 0;
         SLOT_DECL
@@ -258,11 +267,13 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                     const bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < cutoff);
                     if (!__any(can_)) break;
                     const uint64_t ek = k0;
-                    const float ea = a0, eo = o0;
-                    const uint32_t id = key_id(ek);
+                    const uint32_t cell = (uint32_t)(ek & kCellMask);
+                    const uint32_t id = skey_id(ek);
+                    float ea = 0.0f, eo = INFINITY;
+                    if (can_) { ea = PL_ALPHA(cell); eo = PL_OTHER(cell); }
                     if (can_) { // shaders/tracer.cuh:352-367
                         if (COUNT) c.hit_evals++;
-                        last_key = ek;
+                        last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
                         if (a.p.alpha_min < ea) {
                             f3 L;
                             if (!SH) {
@@ -276,15 +287,17 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                         }
                         if (!(T > minT)) alive = false;
                     }
-                    // pop slot 0; an entry whose exit lies inside the segment is re-keyed to its exit event
-                    const bool rekey = can_ && ((((uint32_t)ek) & 1u) == 0u) && (eo < t_hi);
-                    const uint64_t nk = rekey ? mk_key(eo, id, 1) : kKeyInvalid;
+                    // pop slot 0; an entry whose exit lies inside the segment is re-keyed to its exit event and
+                    // keeps its payload cell, otherwise the cell is released
+                    const bool rekey = can_ && ((((uint32_t)ek) & 16u) == 0u) && (eo < t_hi);
+                    const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
+                    pmask = (can_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
                     SLOT_SHIFT(0, 1) SLOT_SHIFT(1, 2) SLOT_SHIFT(2, 3) SLOT_SHIFT(3, 4) SLOT_SHIFT(4, 5) SLOT_SHIFT(5, 6)
-                    k6 = can_ ? kKeyInvalid : k6;
+                    SLOT_SHIFT(6, 7) SLOT_SHIFT(7, 8) SLOT_SHIFT(8, 9) SLOT_SHIFT(9, 10) SLOT_SHIFT(10, 11)
+                    k11 = can_ ? kKeyInvalid : k11;
                     if (__any(rekey)) { // wave-uniform branch
-                        uint64_t dropped_;
-                        SLOT_INSERT(nk, INFINITY, ea, dropped_) // a slot was just freed: nothing can fall off
-                        (void)dropped_;
+                        if (rekey) PL_OTHER(cell) = INFINITY;
+                        SLOT_INSERT(nk) // a slot was just freed: it fits
                     }
                 }
                 if (final_sweep) break;
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                         float te, tx;
                         const bool hit = proxy_slabs(o_g, d_g, r0.w, te, tx) && alive;
                         const uint32_t id = __float_as_uint(r2.w);
-                        const uint64_t ke = mk_key(te, id, 0), kx = mk_key(tx, id, 1);
+                        const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
                         // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
                         const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > pass_lo);
                         const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
@@ -322,9 +335,17 @@ __global__ __launch_bounds__(kBlock, GRT_STREAM_WAVES) void k_render_stream(cons
                             // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
                             const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
                             const float other = (in_e && in_x) ? tx : INFINITY;
-                            uint64_t dropped;
-                            SLOT_INSERT(ins ? k_first : kKeyInvalid, other, alpha, dropped)
+                            // window full: the largest pending key is dropped (the new one or slot 11's) and the lane
+                            // becomes lossy beyond it
+                            const bool full = k11 != kKeyInvalid;
+                            const bool take = ins && (!full || k_first < k11);
+                            const uint64_t dropped = (ins && full) ? (take ? (k11 | kCellMask) : k_first) : kKeyInvalid;
                             cutoff = (dropped < cutoff) ? dropped : cutoff;
+                            const uint32_t cell = full ? (uint32_t)(k11 & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
+                            k11 = (take && full) ? kKeyInvalid : k11;
+                            pmask = take ? (pmask | (1u << cell)) : pmask;
+                            if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; }
+                            SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid)
                         }
                     }
                 } else {
