@@ -37,11 +37,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 def kernel_name(variant, with_mesh, n_proxies, sh_degree):
     """Which kernel grt_render dispatches to (csrc/grt_render.hip: launch_render)."""
     sh = "true" if sh_degree > 0 else "false"
-    if with_mesh or variant == 1:
+    if variant == 1:
         return "grt::k_render<false>"
-    if variant == 3 or (variant == 0 and n_proxies >= 250000):
-        return f"grt::k_render_stream<false, {sh}>"
-    return f"grt::k_render_wave<false, {sh}>"
+    if variant == 2 and not with_mesh:
+        return f"grt::k_render_wave<false, {sh}>"
+    return f"grt::k_render_stream<false, {sh}, {'true' if with_mesh else 'false'}>"
 
 
 def algorithmic_bytes(cnt, pixels, sh_degree, float_out=False):

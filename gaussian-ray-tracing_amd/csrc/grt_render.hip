@@ -533,12 +533,11 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     if (a.n_blocks == 0) return GRT_OK;
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
-    // auto: both wave kernels are bit-identical; the single-pass streaming kernel wins on large scenes (its
-    // iteration count stops growing with the scene), the round-based one on small scenes (cheaper iterations)
-    if (kernel_variant == 0 && wave_ok && a.n_prox >= 250000u) return launch_render_stream(a, count, false, stream, err);
-    if (kernel_variant == 3 && wave_ok) return launch_render_stream(a, count, false, stream, err);
+    // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
+    // Gaussians; the two are bit-identical)
+    if ((kernel_variant == 0 || kernel_variant == 3) && wave_ok) return launch_render_stream(a, count, false, stream, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
-    if (kernel_variant != 1 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
+    if (kernel_variant != 1 && kernel_variant != 2 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
         if (lds > 160 * 1024) {
             if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
             return GRT_ERR_LIMIT;
@@ -566,11 +565,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
         }
         return GRT_OK;
     }
-    if (kernel_variant == 2 && !wave_ok) {
-        if (err) *err = "GRT_OPT_KERNEL=2: the wave kernel needs a mesh-free frame, no ray buffer and BVH height <= 128";
-        return GRT_ERR_INVALID;
-    }
-    if (kernel_variant != 1 && kernel_variant != 3 && wave_ok) return launch_render_wave(a, count, stream, err);
+    if (kernel_variant == 2 && wave_ok) return launch_render_wave(a, count, stream, err);
     if (lds > 160 * 1024) {
         if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
         return GRT_ERR_LIMIT;

@@ -111,10 +111,11 @@ typedef struct {
 } grt_bvh_info;
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
-       GRT_OPT_KERNEL = 2   /* 0 = auto (a wave-cooperative kernel for mesh-free frames — streaming above 250k proxies,
-                               round-based below — per-lane otherwise),
-                               1 = force the per-lane kernel, 2 = force the wave kernel (error if illegal),
-                               3 = single-pass streaming wave kernel where legal, per-lane otherwise */,
+       GRT_OPT_KERNEL = 2   /* 0 = auto (single-pass streaming wave kernel for camera rays, wavefront pipeline for
+                               mesh frames, per-lane kernel for ray buffers),
+                               1 = per-lane kernel everywhere, 2 = round-based wave kernel for camera rays without meshes
+                               (per-lane otherwise),
+                               3 = same as 0 */,
        GRT_OPT_LEAF_MAX = 3 /* max primitives per BVH leaf, 1..8 (default 4); applies to the next build */,
        GRT_OPT_SWIZZLE = 4  /* screen blocks per XCD run in the workgroup->block map (0 = identity) */,
        GRT_OPT_FEEDBACK = 5 /* 1 (default): launch blocks heaviest-first using the previous frame's per-block cost */ };

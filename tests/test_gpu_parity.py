@@ -15,10 +15,11 @@ TOL = 1e-4
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_probes.json")))
 
 
-@pytest.fixture(scope="module", params=[0, 1, 3], ids=["wave", "perlane", "stream"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["stream", "perlane", "wave"])
 def tr(request):
-    """Every parity test runs on each traversal kernel (GRT_OPT_KERNEL): 0 = wave-cooperative (default for
-    mesh-free frames), 1 = per-lane everywhere, 3 = single-pass streaming wave kernel."""
+    """Every parity test runs on each traversal path (GRT_OPT_KERNEL): 0 = default (single-pass streaming wave
+    kernel; wavefront pipeline when meshes are present), 1 = per-lane megakernel everywhere, 2 = round-based
+    wave kernel (per-lane megakernel when meshes are present)."""
     t = grt.Tracer(0)
     t.set_option(grt.OPT_KERNEL, request.param)
     t.kernel_variant = request.param
@@ -71,7 +72,7 @@ def test_c1_10k_256x256_pinhole(tr):
     compare(f32, ref_f32, u8, ref_u8)
     assert cnt["rays"] == rc["rays"] == 256 * 256
     assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
-    if tr.kernel_variant != 3:  # the streaming kernel replaces the k = 7 rounds by (mostly) one pass
+    if tr.kernel_variant != 0:  # the streaming kernel replaces the k = 7 rounds by (mostly) one pass
         assert cnt["rounds"] == rc["rounds"] or abs(cnt["rounds"] - rc["rounds"]) <= 1e-4 * rc["rounds"]
     else:
         assert rc["rays"] <= cnt["rounds"] < rc["rounds"]
