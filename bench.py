@@ -132,6 +132,13 @@ def main():
         tr.render_tiles(p, TILE, TILE, rank, world, my_cnt, out_u8=mine)
     cnt = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
+    # first frame without scheduling feedback (what a cold start / a camera cut costs), for the record
+    tr.set_option(grt.OPT_FEEDBACK, 0)
+    step_cold = (lambda: tr.render(p, out_u8=frame, want_u8=True)) if world == 1 else \
+        (lambda: tr.render_tiles(p, TILE, TILE, rank, world, my_cnt, out_u8=mine))
+    step_cold(); step_cold()
+    cold_ms = tr.last_kernel_ms()
+    tr.set_option(grt.OPT_FEEDBACK, 1)
     names = ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests", "rec_fetches")
     cnt_t = torch.tensor([cnt[k] for k in names], dtype=torch.int64, device=dev)
     if world > 1:
@@ -192,7 +199,10 @@ def main():
                        "proxy_tests_per_ray": round(tot["proxy_tests"] / max(tot["segments"], 1), 1),
                        "rec_fetches_per_ray": round(tot["rec_fetches"] / max(tot["segments"], 1), 2),
                        "bvh_height": info["height"], "n_proxies": info["n_proxies"], "bvh_build_ms": round(info["build_ms"], 2),
-                       "setup_s": round(setup_s, 2), "kernel_variant": args.kernel},
+                       "setup_s": round(setup_s, 2), "kernel_variant": args.kernel,
+                       "scheduling": "blocks launched heaviest-first from the previous frame's per-block cost "
+                                     "(steady state of an interactive viewer); kernel_ms_cold is one frame without it",
+                       "kernel_ms_cold": round(cold_ms, 4)},
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
