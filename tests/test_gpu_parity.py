@@ -253,3 +253,48 @@ def test_c2_100k_window(tr):
     x0, y0, x1, y1 = win
     compare(f32[y0:y1, x0:x1], ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1])
     assert rc["hit_evals"] > 5 * rc["rays"]
+
+
+@pytest.mark.parametrize("eye,fovy", [((0.05, -0.1, 0.2), 75.0), ((1.2, 0.9, -1.4), 40.0), ((0.0, 2.5, 0.3), 100.0)])
+def test_camera_inside_and_around_the_cloud(tr, eye, fovy):
+    """Ray origins inside proxies (exit-only hits), inside BVH boxes (negative box entry distances) and oblique
+    views: the default camera of the other tests always looks down -z from outside the scene."""
+    raw = grt.synth_scene(13, 6000); raw["scale"] = raw["scale"] + np.float32(0.6)
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    p = grt.default_params(112, 80, center, eye=eye, fovy=fovy)
+    tr.upload(acts)
+    u8, f32 = tr.render(p, want_f32=True)
+    sc = O.Scene(acts_to_particles(acts))
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p))
+    compare(f32, ref_f32, u8, ref_u8)
+    assert rc["hit_evals"] > 4 * rc["rays"]
+
+
+def test_needle_and_pancake_gaussians(tr):
+    """Trained-scene-like anisotropy: scales spread over 3 decades per axis (needles, pancakes), large and tiny
+    proxies mixed — stresses the LBVH (huge overlapping boxes) and the slot window."""
+    rng = np.random.default_rng(5)
+    raw = grt.synth_scene(14, 5000)
+    raw["scale"] = (raw["scale"] + rng.normal(0.0, 1.6, size=raw["scale"].shape)).astype(np.float32)
+    acts = grt.activate(raw)
+    p = grt.default_params(96, 96, grt.gaussian_center(acts["pos"]))
+    tr.upload(acts)
+    u8, f32 = tr.render(p, want_f32=True)
+    sc = O.Scene(acts_to_particles(acts))
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p))
+    compare(f32, ref_f32, u8, ref_u8)
+
+
+def test_feedback_scheduling_does_not_change_pixels(tr):
+    """Heaviest-first block order (frame-to-frame feedback) is pure scheduling."""
+    acts, p, sc, op, _ = make_scene(15, 20000, 320, 200, scale_boost=0.3)
+    tr.upload(acts)
+    tr.set_option(grt.OPT_FEEDBACK, 0)
+    a8, af = tr.render(p, want_f32=True)
+    tr.set_option(grt.OPT_FEEDBACK, 1)
+    frames = [tr.render(p, want_f32=True) for _ in range(3)]  # cold order, then two fed-back frames
+    for b8, bf in frames:
+        assert (a8 == b8).all() and (af == bf).all()
+    ref_u8, ref_f32, _ = sc.render(op)
+    compare(af, ref_f32, a8, ref_u8)
