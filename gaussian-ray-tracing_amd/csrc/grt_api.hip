@@ -167,7 +167,10 @@ int grt_create(grt_ctx** out, int device)
     c->device = device;
     if ((e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess ||
         (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipMalloc(&c->d_counters, kNumCounters * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(&c->d_counters, kNumCounters * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipStreamCreate(&c->aux_stream)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipMalloc(&c->d_n_heavy, sizeof(uint32_t))) != hipSuccess) {
         g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
         delete c;
         return GRT_ERR_HIP;
@@ -209,6 +212,10 @@ void grt_destroy(grt_ctx* c)
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    (void)hipFree(c->d_n_heavy);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -220,7 +227,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     if (!c) return GRT_ERR_INVALID;
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
-    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->cost_valid = false; }
+    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : 0; c->cost_valid = false; }
     else if (option == GRT_OPT_SWIZZLE) {
         if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
         c->opt_swizzle = value;
@@ -242,7 +249,7 @@ int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
         if (c) c->err = "grt_upload_gaussians: null argument";
         return GRT_ERR_INVALID;
     }
-    if (n >= (1ull << 27)) { c->err = "grt_upload_gaussians: more than 2^27-1 particles (hit keys carry a 27-bit id)"; return GRT_ERR_LIMIT; }
+    if (n >= (1ull << 26)) { c->err = "grt_upload_gaussians: more than 2^26-1 particles (hit keys carry a 26-bit id)"; return GRT_ERR_LIMIT; }
     CHK(c, hipSetDevice(c->device));
     CHK(c, hipStreamSynchronize(c->stream));
     free_gaussians(c);
@@ -435,6 +442,8 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s)
 {
     a.order = nullptr;
     a.cost = nullptr;
+    a.n_heavy = nullptr;
+    a.heavy_role = 0;
     if (!c->opt_feedback || a.n_blocks == 0) return GRT_OK;
     const uint64_t sig[6] = {a.mode, a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
@@ -456,6 +465,10 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s)
                                      a.n_blocks, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
+        if (c->opt_heavy_split) {
+            count_heavy_blocks(c->d_cost, c->d_order, a.n_blocks, std::max(1u, a.n_blocks / 64u), c->d_n_heavy, s);
+            a.n_heavy = c->d_n_heavy;
+        }
     }
     CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_blocks, s));
     a.cost = c->d_cost;
@@ -489,7 +502,10 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.prec = c->d_prec; a.queue = c->d_queue; a.qcount = c->d_qcount;
     }
     CHK(c, hipEventRecord(c->ev0, s));
-    int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &c->err);
+    LaunchAux aux;
+    aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
+    aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_blocks / 64u) : 0u;
+    int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);
     return rc;

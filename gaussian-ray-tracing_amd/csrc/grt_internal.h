@@ -73,6 +73,8 @@ struct RenderArgs {
     uint32_t swizzle_chunk; // see xcd_swizzle (grt_device.h); 0 = identity
     const uint32_t* order;  // cost-sorted block order from the previous frame (heaviest first) or nullptr
     uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
+    const uint32_t* n_heavy; // device count of leading blocks of `order` that run on the big-window kernel
+    uint32_t heavy_role;     // 0 = every block, 1 = only ranks < *n_heavy, 2 = only ranks >= *n_heavy
     unsigned long long* counters; // 7 x u64 or nullptr
     // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
     float4* prec;      // [n_blocks*256][3] primary mesh-hit records
@@ -80,11 +82,22 @@ struct RenderArgs {
     uint32_t* qcount;  // number of queued rays
 };
 
+// second stream + events used to run the big-window kernel (heavy blocks) beside the default one
+struct LaunchAux {
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    uint32_t heavy_cap = 0; // grid of the big-window launch (0 = no split)
+};
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
-                  std::string* err);
+                  const LaunchAux* aux, std::string* err);
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
-int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err);
+int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
+                         std::string* err);
 constexpr int kNumCounters = 7;
+// number of leading blocks of the cost-sorted order whose cost exceeds 2.5x the median (capped): they run on the
+// big-window kernel
+int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t* d_n_heavy,
+                       hipStream_t stream);
 // heaviest-first block order for the next frame: order = argsort(cost, descending)
 int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
                         void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err);
@@ -133,4 +146,8 @@ struct grt_ctx {
     uint32_t* d_qcount = nullptr;
     size_t wf_cap = 0;
     uint64_t cost_sig[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t* d_n_heavy = nullptr;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int opt_heavy_split = 0; // big-window kernel for the heaviest blocks: off by default (helps the critical path, costs throughput)
 };

@@ -528,14 +528,14 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
 }
 
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
-                  std::string* err)
+                  const LaunchAux* aux, std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
-    if ((kernel_variant == 0 || kernel_variant == 3) && wave_ok) return launch_render_stream(a, count, false, stream, err);
+    if ((kernel_variant == 0 || kernel_variant == 3) && wave_ok) return launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
     if (kernel_variant != 1 && kernel_variant != 2 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
         if (lds > 160 * 1024) {
@@ -552,7 +552,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             return GRT_ERR_HIP;
         }
         hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
-        int rc = launch_render_stream(a, count, true, stream, err);
+        int rc = launch_render_stream(a, count, true, stream, aux, err);
         if (rc != GRT_OK) return rc;
         RenderArgs b = a;
         b.order = nullptr;
