@@ -1,0 +1,61 @@
+"""Every tuning option of the library is pure scheduling / data layout: frames must not change by a single byte."""
+import numpy as np
+import pytest
+
+import grt
+from common import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_options_do_not_change_pixels():
+    acts, p, sc, op, _ = make_scene(17, 30000, 256, 160, scale_boost=0.4)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    ref8, reff = tr.render(p, want_f32=True)
+    ref8, reff = ref8.clone(), reff.clone()
+    for leaf_max in (1, 2, 8):
+        tr.set_option(grt.OPT_LEAF_MAX, leaf_max)
+        tr.upload(acts)
+        for kernel in (0, 1, 2):
+            tr.set_option(grt.OPT_KERNEL, kernel)
+            a8, af = tr.render(p, want_f32=True)
+            assert (a8 == ref8).all() and (af == reff).all(), (leaf_max, kernel)
+    tr.set_option(grt.OPT_LEAF_MAX, 4); tr.set_option(grt.OPT_KERNEL, 0); tr.upload(acts)
+    for swz in (0, 1, 8, 100000):
+        tr.set_option(grt.OPT_SWIZZLE, swz)
+        a8, af = tr.render(p, want_f32=True)
+        assert (a8 == ref8).all() and (af == reff).all(), swz
+    for fb in (0, 1, 5):  # 5 = heaviest-first + big-window kernel for the heaviest blocks on a second stream
+        tr.set_option(grt.OPT_FEEDBACK, fb)
+        for _ in range(3):
+            a8, af = tr.render(p, want_f32=True)
+            assert (a8 == ref8).all() and (af == reff).all(), fb
+    with pytest.raises(grt.GrtError):
+        tr.set_option(grt.OPT_LEAF_MAX, 9)
+    with pytest.raises(grt.GrtError):
+        tr.set_option(99, 1)
+    tr.close()
+
+
+def test_split_launch_with_mesh_and_tiles():
+    """Big-window split launch (GRT_OPT_FEEDBACK = 5) through the wavefront pipeline and the tile entry point."""
+    import torch
+    acts, p, sc, op, center = make_scene(18, 20000, 192, 128, scale_boost=0.4, mesh_type=grt.MIRROR, max_bounces=3)
+    pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_meshes([grt.sphere_mesh(pos, tess_u=32, tess_v=16)])
+    tr.set_option(grt.OPT_FEEDBACK, 0)
+    ref8, _ = tr.render(p)
+    ref8 = ref8.clone()
+    tr.set_option(grt.OPT_FEEDBACK, 5)
+    for _ in range(3):
+        a8, _ = tr.render(p)
+        assert (a8 == ref8).all()
+    tiles8 = torch.zeros((6 * 4, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+    for _ in range(3):
+        tr.render_tiles(p, 32, 32, 0, 1, 24, out_u8=tiles8)
+    img = tiles8.reshape(4, 6, 32, 32, 3).permute(0, 2, 1, 3, 4).reshape(128, 192, 3)
+    assert (img == ref8).all()
+    tr.close()
