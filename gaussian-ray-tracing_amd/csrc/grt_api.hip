@@ -227,7 +227,9 @@ int grt_set_option(grt_ctx* c, int option, int value)
     if (!c) return GRT_ERR_INVALID;
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
-    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : 0; c->cost_valid = false; }
+    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : ((value & 2) ? 0 : 2); c->cost_valid = false; }
+    else if (option == 6) { c->opt_heavy_thr_x2 = std::max(2, value); }   // tuning knobs of the split launch
+    else if (option == 7) { c->opt_heavy_cap_div = std::max(1, value); }
     else if (option == GRT_OPT_SWIZZLE) {
         if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
         c->opt_swizzle = value;
@@ -465,8 +467,9 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s)
                                      a.n_blocks, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
-        if (c->opt_heavy_split) {
-            count_heavy_blocks(c->d_cost, c->d_order, a.n_blocks, std::max(1u, a.n_blocks / 64u), c->d_n_heavy, s);
+        if (c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u)) {
+            count_heavy_blocks(c->d_cost, c->d_order, a.n_blocks, std::max(1u, a.n_blocks / (uint32_t)c->opt_heavy_cap_div),
+                               (uint32_t)c->opt_heavy_thr_x2, c->d_n_heavy, s);
             a.n_heavy = c->d_n_heavy;
         }
     }
@@ -504,7 +507,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     CHK(c, hipEventRecord(c->ev0, s));
     LaunchAux aux;
     aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
-    aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_blocks / 64u) : 0u;
+    aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_blocks / (uint32_t)c->opt_heavy_cap_div) : 0u;
+    aux.force_big = c->opt_kernel == 4;
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);

@@ -256,11 +256,11 @@ int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_s
 }
 
 __global__ void k_count_heavy(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ order, uint32_t n,
-                              uint32_t cap, uint32_t* __restrict__ out)
+                              uint32_t cap, uint32_t thr_x2, uint32_t* __restrict__ out)
 {
     if (threadIdx.x || blockIdx.x) return;
     const uint32_t median = cost[order[n / 2]];
-    const uint32_t thr = 4u * median;
+    const uint32_t thr = (median * thr_x2) >> 1;
     uint32_t lo = 0, hi = n < cap ? n : cap;              // order is sorted by cost, descending
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -269,10 +269,10 @@ __global__ void k_count_heavy(const uint32_t* __restrict__ cost, const uint32_t*
     *out = lo;
 }
 
-int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t* d_n_heavy,
-                       hipStream_t stream)
+int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t thr_x2,
+                       uint32_t* d_n_heavy, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(64), 0, stream, d_cost, d_order, n, cap, d_n_heavy);
+    hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(64), 0, stream, d_cost, d_order, n, cap, thr_x2, d_n_heavy);
     return GRT_OK;
 }
 

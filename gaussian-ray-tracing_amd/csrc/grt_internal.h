@@ -87,6 +87,7 @@ struct LaunchAux {
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     uint32_t heavy_cap = 0; // grid of the big-window launch (0 = no split)
+    bool force_big = false; // GRT_OPT_KERNEL = 4: every block on the big-window kernel (testing)
 };
 int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
                   const LaunchAux* aux, std::string* err);
@@ -96,8 +97,8 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
 constexpr int kNumCounters = 7;
 // number of leading blocks of the cost-sorted order whose cost exceeds 2.5x the median (capped): they run on the
 // big-window kernel
-int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t* d_n_heavy,
-                       hipStream_t stream);
+int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t thr_x2,
+                       uint32_t* d_n_heavy, hipStream_t stream);
 // heaviest-first block order for the next frame: order = argsort(cost, descending)
 int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
                         void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err);
@@ -149,5 +150,9 @@ struct grt_ctx {
     uint32_t* d_n_heavy = nullptr;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int opt_heavy_split = 0; // big-window kernel for the heaviest blocks: off by default (helps the critical path, costs throughput)
+    int opt_heavy_thr_x2 = 4;   // heavy = cost > thr_x2/2 x median
+    int opt_heavy_cap_div = 8;  // at most n_blocks / cap_div heavy blocks
+    // big-window kernel for the heaviest blocks: 0 off, 1 on, 2 auto = on for small launches (<= 3072 blocks: a
+    // multi-GPU rank's share of a 1080p frame), where the heaviest tile and not throughput bounds the frame
+    int opt_heavy_split = 2;
 };

@@ -535,7 +535,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
-    if ((kernel_variant == 0 || kernel_variant == 3) && wave_ok) return launch_render_stream(a, count, false, stream, aux, err);
+    if ((kernel_variant == 0 || kernel_variant == 3 || kernel_variant == 4) && wave_ok) return launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
     if (kernel_variant != 1 && kernel_variant != 2 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
         if (lds > 160 * 1024) {

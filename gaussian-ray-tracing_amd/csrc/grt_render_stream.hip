@@ -85,8 +85,11 @@ __device__ __forceinline__ float wave_min(float v)
 #undef GRT_WAVES
 #undef GRT_KERNEL_NAME
 
-// big-window kernel: 24-particle window, 2 waves per SIMD (no spills) — for the blocks marked heavy
-#define GRT_KS 24
+// big-window kernel: 32-particle window, 2 waves per SIMD (no spills) — for the blocks marked heavy
+#ifndef GRT_BIG_KS
+#define GRT_BIG_KS 32
+#endif
+#define GRT_KS GRT_BIG_KS
 #define GRT_WAVES 2
 #define GRT_KERNEL_NAME k_render_stream_big
 #include "grt_render_stream_body.inc"
@@ -116,7 +119,7 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
     if (!split) {
         RenderArgs b = a;
         b.heavy_role = 0;
-        hipLaunchKernelGGL(pick(false, count, sh, mesh), dim3(a.n_blocks), dim3(kBlock), 0, stream, b);
+        hipLaunchKernelGGL(pick(aux && aux->force_big, count, sh, mesh), dim3(a.n_blocks), dim3(kBlock), 0, stream, b);
     } else {
         // heavy blocks (the first *n_heavy ranks of the cost-sorted order) on the big-window kernel, on a second
         // stream so that both launches share the GPU; the main stream joins it before anything else runs

@@ -118,9 +118,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                3 = same as 0 */,
        GRT_OPT_LEAF_MAX = 3 /* max primitives per BVH leaf, 1..8 (default 4); applies to the next build */,
        GRT_OPT_SWIZZLE = 4  /* screen blocks per XCD run in the workgroup->block map (0 = identity) */,
-       GRT_OPT_FEEDBACK = 5 /* 1 (default): launch blocks heaviest-first using the previous frame's per-block cost;
-                               5: additionally run the heaviest ~1.5 % of the blocks on the 24-slot big-window kernel
-                               on a second stream (shorter critical path, lower throughput); 0: off */ };
+       GRT_OPT_FEEDBACK = 5 /* 1 (default): launch blocks heaviest-first using the previous frame's per-block cost; in
+                               launches of <= 3072 blocks (a multi-GPU rank's share of a frame) additionally run the
+                               heaviest blocks on the 32-slot big-window kernel on a second stream (shorter critical
+                               path).  3: heaviest-first only.  5: big-window split always.  0: off */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

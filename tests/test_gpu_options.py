@@ -26,7 +26,7 @@ def test_options_do_not_change_pixels():
         tr.set_option(grt.OPT_SWIZZLE, swz)
         a8, af = tr.render(p, want_f32=True)
         assert (a8 == ref8).all() and (af == reff).all(), swz
-    for fb in (0, 1, 5):  # 5 = heaviest-first + big-window kernel for the heaviest blocks on a second stream
+    for fb in (0, 1, 3, 5):  # 5 = heaviest-first + big-window kernel for the heaviest blocks on a second stream
         tr.set_option(grt.OPT_FEEDBACK, fb)
         for _ in range(3):
             a8, af = tr.render(p, want_f32=True)
