@@ -228,8 +228,8 @@ int grt_set_option(grt_ctx* c, int option, int value)
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
     else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : ((value & 2) ? 0 : 2); c->cost_valid = false; }
-    else if (option == 6) { c->opt_heavy_thr_x2 = std::max(2, value); }   // tuning knobs of the split launch
-    else if (option == 7) { c->opt_heavy_cap_div = std::max(1, value); }
+    else if (option == GRT_OPT_HEAVY_THRESHOLD_X2) { c->opt_heavy_thr_x2 = std::max(2, value); }
+    else if (option == GRT_OPT_HEAVY_CAP_DIV) { c->opt_heavy_cap_div = std::max(1, value); }
     else if (option == GRT_OPT_SWIZZLE) {
         if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
         c->opt_swizzle = value;

@@ -230,7 +230,10 @@ int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f_dc, flo
     for (size_t k = 0; k < names.size(); k++) {
         for (size_t j = 0; j < h.props.size(); j++)
             if (h.props[j].name == names[k]) idx[k] = (int)j;
-        if (idx[k] < 0) { g_host_err = "PLY: missing property '" + names[k] + "'"; return GRT_ERR_IO; }
+        // Exports trained at SH degree < 3 carry fewer f_rest_* columns: the missing
+        // coefficients are zero.  Every other property is required, as the reference's getProperty() is.
+        const bool is_rest = names[k].compare(0, 7, "f_rest_") == 0;
+        if (idx[k] < 0 && !is_rest) { g_host_err = "PLY: missing property '" + names[k] + "'"; return GRT_ERR_IO; }
     }
     auto store = [&](uint64_t i, size_t k, float v) {
         if (k < 3) pos[i * 3 + k] = v;
@@ -250,6 +253,7 @@ int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f_dc, flo
             if ((uint64_t)f.gcount() != cnt * h.stride) { g_host_err = "PLY: truncated vertex data"; return GRT_ERR_IO; }
             for (uint64_t i = 0; i < cnt; i++)
                 for (size_t k = 0; k < names.size(); k++) {
+                    if (idx[k] < 0) { store(base + i, k, 0.0f); continue; }
                     const PlyProp& pr = h.props[idx[k]];
                     store(base + i, k, prop_as_float(buf.data() + i * h.stride + pr.offset, pr));
                 }
@@ -259,7 +263,7 @@ int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f_dc, flo
         for (uint64_t i = 0; i < n; i++) {
             for (size_t j = 0; j < h.props.size(); j++)
                 if (!(f >> row[j])) { g_host_err = "PLY: truncated ascii vertex data"; return GRT_ERR_IO; }
-            for (size_t k = 0; k < names.size(); k++) store(i, k, (float)row[idx[k]]);
+            for (size_t k = 0; k < names.size(); k++) store(i, k, idx[k] < 0 ? 0.0f : (float)row[idx[k]]);
         }
     }
     return GRT_OK;

@@ -121,7 +121,9 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_FEEDBACK = 5 /* 1 (default): launch blocks heaviest-first using the previous frame's per-block cost; in
                                launches of <= 3072 blocks (a multi-GPU rank's share of a frame) additionally run the
                                heaviest blocks on the 32-slot big-window kernel on a second stream (shorter critical
-                               path).  3: heaviest-first only.  5: big-window split always.  0: off */ };
+                               path).  3: heaviest-first only.  5: big-window split always.  0: off */,
+       GRT_OPT_HEAVY_THRESHOLD_X2 = 6 /* a block is heavy when its cost exceeds value/2 x the median cost (default 4) */,
+       GRT_OPT_HEAVY_CAP_DIV = 7      /* at most n_blocks / value blocks go to the big-window kernel (default 8) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

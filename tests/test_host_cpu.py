@@ -140,3 +140,21 @@ def test_oracle_mesh_bvh_equals_bruteforce(mesh_type):
     _, fb, cb = sc.render(op)
     assert fa.tobytes() == fb.tobytes()
     assert ca["segments"] > ca["rays"] or mesh_type == grt.NORMAL  # secondary segments exist
+
+
+def test_ply_with_fewer_sh_bands_reads_missing_f_rest_as_zero(tmp_path):
+    """3DGS exports trained at SH degree 1 carry only f_rest_0..8."""
+    raw = grt.synth_scene(6, 40)
+    names = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{k}" for k in range(9)] + ["opacity"] + \
+            [f"scale_{k}" for k in range(3)] + [f"rot_{k}" for k in range(4)]
+    cols = np.concatenate([raw["pos"], raw["f_dc"], raw["f_rest"][:, :9], raw["opacity"][:, None], raw["scale"], raw["rot"]], 1)
+    q = str(tmp_path / "deg1.ply")
+    with open(q, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex 40\n" +
+                 "".join(f"property float {n}\n" for n in names) + "end_header\n").encode())
+        f.write(np.ascontiguousarray(cols, np.float32).tobytes())
+    back = grt.read_ply(q)
+    assert back["f_rest"][:, :9].tobytes() == np.ascontiguousarray(raw["f_rest"][:, :9]).tobytes()
+    assert (back["f_rest"][:, 9:] == 0).all()
+    for k in ("pos", "f_dc", "opacity", "scale", "rot"):
+        assert back[k].tobytes() == raw[k].tobytes()
