@@ -313,7 +313,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
             (void)hipFree(c->d_rec);
             c->d_rec = nullptr;
             c->cap_rec = 0;
-            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4))) != hipSuccess) {
+            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4) + 256)) != hipSuccess) {
                 c->err = std::string("grt_build_bvh: hipMalloc(rec): ") + hipGetErrorString(e);
                 rc = GRT_ERR_HIP;
             } else c->cap_rec = m;
@@ -419,6 +419,7 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     a->p = *p;
     a->rec = c->d_rec;
     a->nodes = c->gbvh.nodes;
+    a->wnodes = c->gbvh.wnodes;
     a->root_ref = c->gbvh.root_ref;
     a->n_prox = c->gbvh.n_prims;
     a->color0 = c->d_color0;

@@ -255,6 +255,52 @@ int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_s
     return GRT_OK;
 }
 
+// 4-wide view: wide record i = the (up to four) grandchildren of binary node i; a child that is a leaf range stays
+// as it is.  Internal refs keep pointing at binary node indices, each of which has its own wide record.
+__global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restrict__ wn)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1) return;
+    const float4 q0 = nodes[(size_t)i * 4], q1 = nodes[(size_t)i * 4 + 1], q2 = nodes[(size_t)i * 4 + 2],
+                 q3 = nodes[(size_t)i * 4 + 3];
+    float box[4][6];
+    uint32_t ref[4];
+    int ne = 0;
+    const uint32_t c[2] = {__float_as_uint(q3.x), __float_as_uint(q3.y)};
+    const float cb[2][6] = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y}, {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w}};
+    for (int k = 0; k < 2; k++) {
+        if (c[k] & kLeafBit) {
+            for (int j = 0; j < 6; j++) box[ne][j] = cb[k][j];
+            ref[ne++] = c[k];
+        } else {
+            const size_t b = (size_t)c[k] * 4;
+            const float4 g0 = nodes[b], g1 = nodes[b + 1], g2 = nodes[b + 2], g3 = nodes[b + 3];
+            const float gb[2][6] = {{g0.x, g0.y, g0.z, g0.w, g1.x, g1.y}, {g1.z, g1.w, g2.x, g2.y, g2.z, g2.w}};
+            for (int j = 0; j < 6; j++) box[ne][j] = gb[0][j];
+            ref[ne++] = __float_as_uint(g3.x);
+            for (int j = 0; j < 6; j++) box[ne][j] = gb[1][j];
+            ref[ne++] = __float_as_uint(g3.y);
+        }
+    }
+    for (; ne < 4; ne++) { // unused child: ref kNoRoot (the traversal tests the ref; the slab test is symmetric in lo/hi)
+        box[ne][0] = box[ne][1] = box[ne][2] = 1.0f;
+        box[ne][3] = box[ne][4] = box[ne][5] = -1.0f;
+        ref[ne] = kNoRoot;
+    }
+    float4* w = wn + (size_t)i * 8;
+    // per child: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z) — 8-byte pairs the traversal can swap with scalar ops
+#define GRT_WB(c, j) box[c][(j) == 0 ? 0 : (j) == 1 ? 1 : (j) == 2 ? 3 : (j) == 3 ? 4 : (j) == 4 ? 2 : 5]
+    w[0] = make_float4(GRT_WB(0, 0), GRT_WB(0, 1), GRT_WB(0, 2), GRT_WB(0, 3));
+    w[1] = make_float4(GRT_WB(0, 4), GRT_WB(0, 5), GRT_WB(1, 0), GRT_WB(1, 1));
+    w[2] = make_float4(GRT_WB(1, 2), GRT_WB(1, 3), GRT_WB(1, 4), GRT_WB(1, 5));
+    w[3] = make_float4(GRT_WB(2, 0), GRT_WB(2, 1), GRT_WB(2, 2), GRT_WB(2, 3));
+    w[4] = make_float4(GRT_WB(2, 4), GRT_WB(2, 5), GRT_WB(3, 0), GRT_WB(3, 1));
+    w[5] = make_float4(GRT_WB(3, 2), GRT_WB(3, 3), GRT_WB(3, 4), GRT_WB(3, 5));
+#undef GRT_WB
+    w[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
+    w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void k_count_heavy(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ order, uint32_t n,
                               uint32_t cap, uint32_t thr_x2, uint32_t* __restrict__ out)
 {
@@ -278,6 +324,7 @@ int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t
 
 void free_bvh(DevBvh* b)
 {
+    if (b->wnodes) (void)hipFree(b->wnodes);
     if (b->nodes) (void)hipFree(b->nodes);
     if (b->order) (void)hipFree(b->order);
     *b = DevBvh();
@@ -383,8 +430,12 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         out->height = root_level;
         out->root_ref = 0;
     }
+    if (out->wnodes) (void)hipFree(out->wnodes);
+    out->wnodes = nullptr;
+    HIPCHK(hipMalloc(&out->wnodes, sizeof(float4) * 8 * (size_t)(m - 1) + 256));
     if (leaf_max > 1)
         hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
+    hipLaunchKernelGGL(k_widen, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->wnodes);
     HIPCHK(hipStreamSynchronize(stream));
 done:
     HIPCHK(hipGetLastError());

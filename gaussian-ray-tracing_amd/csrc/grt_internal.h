@@ -27,6 +27,9 @@ constexpr uint32_t kNoRoot = 0xFFFFFFFFu;
 //   q3 = (child0, child1, 0, 0) as raw bits
 struct DevBvh {
     float4* nodes = nullptr;   // [(n_prims-1) * 4]
+    float4* wnodes = nullptr;  // [(n_prims-1) * 8] 4-wide view of the same tree (two binary levels per record):
+                               //   24 floats = 4 child boxes, each (lo.x lo.y | hi.x hi.y | lo.z hi.z),
+                               //   W6 = 4 child refs, W7 pad; an unused child has ref kNoRoot
     uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
     uint32_t n_prims = 0;      // valid primitives (leaves)
     uint32_t height = 0;       // levels of internal nodes (bounds the traversal stack)
@@ -47,6 +50,7 @@ struct RenderArgs {
     // Gaussian scene
     const float4* rec;    // [n_prox*4] Morton-sorted proxy records (see grt_api.hip: k_gather_records)
     const float4* nodes;
+    const float4* wnodes; // 4-wide records (streaming kernel)
     uint32_t root_ref;
     uint32_t n_prox;
     const float4* color0; // [n_particles] degree-0 radiance by ORIGINAL particle id

@@ -64,10 +64,11 @@ __device__ __forceinline__ float wave_min(float v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t x = __float_as_uint(v);
-    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
-    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xF, 0xF, false)); // row_half_mirror
-    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false)); // row_mirror
+    // bound_ctrl:1 lets the compiler fold each DPP move into the v_min_u32 itself (one VALU op per step)
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true)); // row_half_mirror
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true)); // row_mirror
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
     return __uint_as_float(min(min(a, b), min(c, d)));
@@ -76,9 +77,54 @@ __device__ __forceinline__ float wave_min(float v)
 #endif
 }
 
+// votes straight on the lane mask (the __any/__ballot wrappers go through an int and cost two extra VALU ops)
+__device__ __forceinline__ uint64_t wave_ballot(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return p ? 1ull : 0ull;
+#endif
+}
+__device__ __forceinline__ bool wave_any(bool p) { return wave_ballot(p) != 0ull; }
+// max(v, +0) for a non-NaN float as one integer max (negative floats are negative ints)
+__device__ __forceinline__ float clamp0(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+// Profiling build (make WPROF=1, never shipped): the counters then hold WAVE-level trip counts of the kernel's
+// sections instead of per-lane event counts — rays: pops, node_visits: wide nodes, fetches: leaf particles,
+// proxy_tests: exact slab tests run, segments: insert blocks, hit_evals: compositing steps, rounds: re-key blocks.
+#ifdef GRT_WPROF
+#define GRT_W_DECL Cnt w;
+#define GRT_W(f) w.f++;
+#define GRT_W_FLUSH c = (lane == 0) ? w : Cnt();
+#else
+#define GRT_W_DECL
+#define GRT_W(f)
+#define GRT_W_FLUSH
+#endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); } // v_pk_fma_f32
+
+// two wave-uniform floats as one 64-bit scalar (an aligned SGPR pair) and back
+__device__ __forceinline__ uint64_t pack2(float a, float b)
+{
+    return (uint64_t)__float_as_uint(a) | ((uint64_t)__float_as_uint(b) << 32);
+}
+__device__ __forceinline__ v2f unpack2(uint64_t u)
+{
+    return v2f{__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32))};
+}
+
 // default kernel: 12-particle window, 4 waves per SIMD (128 VGPRs; a handful spill to scratch)
 #define GRT_KS 12
-#define GRT_WAVES 4
+#ifndef GRT_DEF_WAVES
+#define GRT_DEF_WAVES 4
+#endif
+#define GRT_WAVES GRT_DEF_WAVES
+#ifndef GRT_FBANKS
+#define GRT_FBANKS 1
+#endif
 #define GRT_KERNEL_NAME k_render_stream
 #include "grt_render_stream_body.inc"
 #undef GRT_KS
