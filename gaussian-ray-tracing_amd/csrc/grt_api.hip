@@ -97,6 +97,26 @@ __global__ void k_gather_records(const float* __restrict__ pos, const float* __r
     rec[(size_t)j * 4 + 3] = make_float4(A[6], A[7], A[8], 0.0f);
 }
 
+// Eye records: everything in the proxy test that depends on the ray ORIGIN only.  Camera rays share one origin,
+// so the streaming kernel reads these (wave-uniform, scalar loads) instead of recomputing them on every lane:
+//   (o_g.x o_g.y o_g.z cc)      o_g = A (eye - mu), cc = |o_g|^2 - R^2 of the pre-test sphere
+// — each by the very operation sequence the kernels use per lane (grt_device.h), so results are bit-identical.
+// Rebuilt only when the eye moves or the records change: one pass over the particles (~20 us per million).
+__global__ void k_eye_records(const float4* __restrict__ rec, uint32_t m, float ex, float ey, float ez,
+                              float4* __restrict__ erec)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const float4 r0 = rec[(size_t)j * 4], r1 = rec[(size_t)j * 4 + 1], r2 = rec[(size_t)j * 4 + 2],
+                 r3 = rec[(size_t)j * 4 + 3];
+    m33 A;
+    A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+    A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+    A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+    const f3 o_g = matvec(A, sub3(mk3(ex, ey, ez), mk3(r0.x, r0.y, r0.z)));
+    erec[j] = make_float4(o_g.x, o_g.y, o_g.z, proxy_sphere_cc(o_g, r0.w));
+}
+
 // degree-0 radiance max(0.5 + SH_C0 * sh[0], 0) (shaders/tracer.cuh:223,263), by original id
 __global__ void k_color0(const float* __restrict__ sh, uint32_t n, float4* __restrict__ color0)
 {
@@ -206,6 +226,7 @@ void grt_destroy(grt_ctx* c)
     free_meshes(c);
     free_bvh(&c->gbvh);
     (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_erec);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
     (void)hipFree(c->d_sort_tmp);
@@ -311,9 +332,11 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         const uint32_t m = c->gbvh.n_prims;
         if (c->cap_rec < m) {
             (void)hipFree(c->d_rec);
-            c->d_rec = nullptr;
+            (void)hipFree(c->d_erec);
+            c->d_rec = c->d_erec = nullptr;
             c->cap_rec = 0;
-            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4) + 256)) != hipSuccess) {
+            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4) + 256)) != hipSuccess ||
+                (e = hipMalloc(&c->d_erec, (size_t)m * sizeof(float4) + 256)) != hipSuccess) {
                 c->err = std::string("grt_build_bvh: hipMalloc(rec): ") + hipGetErrorString(e);
                 rc = GRT_ERR_HIP;
             } else c->cap_rec = m;
@@ -332,6 +355,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     (void)hipFree(d_s); (void)hipFree(d_lo); (void)hipFree(d_hi);
     c->have_timing = false;
     c->cost_valid = false;
+    c->erec_valid = false;
     if (rc == GRT_OK) c->built = true;
     return rc;
 }
@@ -441,40 +465,41 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // launch.  Pure scheduling: pixels do not depend on the order.  A viewer's consecutive frames are nearly identical,
 // which is what makes last frame's cost a good predictor; the first frame (or any change of size / mode) runs in
 // the default XCD-chunked order.
-static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s)
+static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units)
 {
     a.order = nullptr;
     a.cost = nullptr;
     a.n_heavy = nullptr;
     a.heavy_role = 0;
-    if (!c->opt_feedback || a.n_blocks == 0) return GRT_OK;
-    const uint64_t sig[6] = {a.mode, a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
+    a.n_units = n_units;
+    if (!c->opt_feedback || n_units == 0) return GRT_OK;
+    const uint64_t sig[6] = {a.mode | ((uint64_t)n_units << 8), a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
                              ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
-    if (c->cost_cap < a.n_blocks) {
+    if (c->cost_cap < n_units) {
         (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
         c->d_cost = c->d_order = c->d_skeys = c->d_svals = nullptr;
         c->cost_cap = 0;
         c->cost_valid = false;
-        CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * a.n_blocks));
-        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * a.n_blocks));
-        CHK(c, hipMalloc(&c->d_skeys, sizeof(uint32_t) * 2 * a.n_blocks));
-        CHK(c, hipMalloc(&c->d_svals, sizeof(uint32_t) * a.n_blocks));
-        c->cost_cap = a.n_blocks;
+        CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
+        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * n_units));
+        CHK(c, hipMalloc(&c->d_skeys, sizeof(uint32_t) * 2 * n_units));
+        CHK(c, hipMalloc(&c->d_svals, sizeof(uint32_t) * n_units));
+        c->cost_cap = n_units;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     if (same) {
         int rc = sort_blocks_by_cost(c->d_cost, c->d_order, c->d_skeys, c->d_svals, &c->d_sort_tmp, &c->sort_tmp_bytes,
-                                     a.n_blocks, s, &c->err);
+                                     n_units, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
         if (c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u)) {
-            count_heavy_blocks(c->d_cost, c->d_order, a.n_blocks, std::max(1u, a.n_blocks / (uint32_t)c->opt_heavy_cap_div),
+            count_heavy_blocks(c->d_cost, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
                                (uint32_t)c->opt_heavy_thr_x2, c->d_n_heavy, s);
             a.n_heavy = c->d_n_heavy;
         }
     }
-    CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_blocks, s));
+    CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
     a.cost = c->d_cost;
     memcpy(c->cost_sig, sig, sizeof(sig));
     c->cost_valid = true;
@@ -486,7 +511,11 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     CHK(c, hipSetDevice(c->device));
     {
-        int rcf = prepare_feedback(c, a, s);
+        // the streaming kernel runs one 8x8 tile (one wave) per workgroup and is scheduled per tile; the other
+        // kernels per 16x16 block (same test as launch_render)
+        const uint32_t h = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
+        const bool stream_kernel = c->opt_kernel != 1 && c->opt_kernel != 2 && a.mode != 2 && h <= 120;
+        int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks);
         if (rcf != GRT_OK) return rcf;
     }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
@@ -506,9 +535,21 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.prec = c->d_prec; a.queue = c->d_queue; a.qcount = c->d_qcount;
     }
     CHK(c, hipEventRecord(c->ev0, s));
+    a.erec = nullptr;
+    if (a.mode != 2 && c->gbvh.n_prims && c->d_erec && c->opt_kernel != 1 && c->opt_kernel != 2) {
+        // streaming kernel on camera rays: refresh the eye records when the eye moved (part of the timed frame)
+        const uint32_t m = c->gbvh.n_prims;
+        if (!c->erec_valid || memcmp(c->erec_eye, a.p.eye, sizeof(c->erec_eye)) != 0) {
+            hipLaunchKernelGGL(k_eye_records, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0], a.p.eye[1],
+                               a.p.eye[2], c->d_erec);
+            memcpy(c->erec_eye, a.p.eye, sizeof(c->erec_eye));
+            c->erec_valid = true;
+        }
+        a.erec = c->d_erec;
+    }
     LaunchAux aux;
     aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
-    aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_blocks / (uint32_t)c->opt_heavy_cap_div) : 0u;
+    aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_units / (uint32_t)c->opt_heavy_cap_div) : 0u; // in scheduling units
     aux.force_big = c->opt_kernel == 4;
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));

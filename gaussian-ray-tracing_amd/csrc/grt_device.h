@@ -109,10 +109,10 @@ __device__ __forceinline__ void slab_project(f3 v, float a[10])
 }
 
 // exact proxy test; same operation sequence as oracle/grt_oracle.c:proxy_slabs
-__device__ __forceinline__ bool proxy_slabs(f3 o_g, f3 d_g, float s, float& t_entry, float& t_exit)
+// a[] = slab_project(o_g), formed by the caller (per lane, or once per eye and particle: k_eye_records)
+__device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float s, float& t_entry, float& t_exit)
 {
-    float a[10], b[10];
-    slab_project(o_g, a);
+    float b[10];
     slab_project(d_g, b);
     const float s3 = s * kSqrt3;
     float nn = 0.0f, nd = 0.0f, fn = 0.0f, fd = 0.0f;
@@ -134,16 +134,30 @@ __device__ __forceinline__ bool proxy_slabs(f3 o_g, f3 d_g, float s, float& t_en
     t_exit = fn / fd;
     return t_entry <= t_exit;
 }
+__device__ __forceinline__ bool proxy_slabs(f3 o_g, f3 d_g, float s, float& t_entry, float& t_exit)
+{
+    float a[10];
+    slab_project(o_g, a);
+    return proxy_slabs_pre(a, d_g, s, t_entry, t_exit);
+}
 
 // Conservative pre-test (culling only, never decides a hit): can the ray touch the sphere that circumscribes
 // the proxy icosahedron in Gaussian space (circumradius / inradius = 1.2584086)?  The 4e-6 slack covers the
 // fp32 rounding of the three dot products; when |o_g| is so large that the slack exceeds R^2 the test simply
 // passes everything.
-__device__ __forceinline__ bool proxy_sphere_maybe(f3 o_g, f3 d_g, float s)
+__device__ __forceinline__ float proxy_sphere_cc(f3 o_g, float s)
 {
     const float R = 1.2585f * s;
-    const float b = dot3(o_g, d_g), aa = dot3(d_g, d_g), cc = dot3(o_g, o_g) - R * R;
+    return dot3(o_g, o_g) - R * R;
+}
+__device__ __forceinline__ bool proxy_sphere_maybe_pre(f3 o_g, float cc, f3 d_g)
+{
+    const float b = dot3(o_g, d_g), aa = dot3(d_g, d_g);
     return (cc <= 0.0f) || (b * b * (1.0f + 4e-6f) >= aa * cc);
+}
+__device__ __forceinline__ bool proxy_sphere_maybe(f3 o_g, f3 d_g, float s)
+{
+    return proxy_sphere_maybe_pre(o_g, proxy_sphere_cc(o_g, s), d_g);
 }
 
 // computeResponse — shaders/tracer.cuh:187-214, given o_g = A(o-mu), d_g = A d already formed

@@ -49,6 +49,7 @@ struct RenderArgs {
     grt_params p;
     // Gaussian scene
     const float4* rec;    // [n_prox*4] Morton-sorted proxy records (see grt_api.hip: k_gather_records)
+    const float4* erec;   // [n_prox] per-eye part of the proxy test, same order (k_eye_records); camera frames only
     const float4* nodes;
     const float4* wnodes; // 4-wide records (streaming kernel)
     uint32_t root_ref;
@@ -75,6 +76,7 @@ struct RenderArgs {
     uint64_t n_rays;
     uint32_t n_blocks;
     uint32_t swizzle_chunk; // see xcd_swizzle (grt_device.h); 0 = identity
+    uint32_t n_units;      // scheduling units of order[] / cost[]: n_blocks (256-thread kernels) or 4 * n_blocks (streaming: one per 8x8 tile)
     const uint32_t* order;  // cost-sorted block order from the previous frame (heaviest first) or nullptr
     uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
     const uint32_t* n_heavy; // device count of leading blocks of `order` that run on the big-window kernel
@@ -126,6 +128,9 @@ struct grt_ctx {
     float alpha_min = 0.01f;
     grt::DevBvh gbvh;
     float4* d_rec = nullptr;
+    float4* d_erec = nullptr;   // per-eye records of the streaming kernel (grt_api.hip: k_eye_records)
+    float erec_eye[3] = {0, 0, 0};
+    bool erec_valid = false;
     size_t cap_rec = 0;
     bool built = false;
     float build_ms = 0.f;

@@ -33,7 +33,9 @@ namespace grt {
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of RenderArgs::n_blocks, order[], cost[])
+constexpr int kWG = 64;     // workgroup = ONE wave: a finished wave frees its slot at once instead of waiting
+                            // for the slowest of four (tile costs within a block differ a lot)
 constexpr uint64_t kCellMask = 31ull; // payload-cell bits of a slot key
 __device__ __forceinline__ uint64_t mk_skey(float t, uint32_t id, uint32_t is_exit)
 {
@@ -94,9 +96,17 @@ __device__ __forceinline__ float clamp0(float v) { return __int_as_float(max(__f
 // sections instead of per-lane event counts — rays: pops, node_visits: wide nodes, fetches: leaf particles,
 // proxy_tests: exact slab tests run, segments: insert blocks, hit_evals: compositing steps, rounds: re-key blocks.
 #ifdef GRT_WPROF
-#define GRT_W_DECL Cnt w;
+#define GRT_W_DECL Cnt w; const uint64_t w_t0 = wall_clock64();
 #define GRT_W(f) w.f++;
-#define GRT_W_FLUSH c = (lane == 0) ? w : Cnt();
+#define GRT_W_FLUSH                                                                                        \
+    c = (lane == 0) ? w : Cnt();                                                                           \
+    if (a.outf && lane == 0 && write) { /* timeline: (start, end) in 100 MHz ticks and the hardware id */  \
+        uint32_t hwid_;                                                                                    \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid_));                                \
+        a.outf[out_idx * 3] = __uint_as_float((uint32_t)w_t0);                                             \
+        a.outf[out_idx * 3 + 1] = __uint_as_float((uint32_t)wall_clock64());                               \
+        a.outf[out_idx * 3 + 2] = __uint_as_float(hwid_);                                                  \
+    }
 #else
 #define GRT_W_DECL
 #define GRT_W(f)
@@ -165,7 +175,7 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
     if (!split) {
         RenderArgs b = a;
         b.heavy_role = 0;
-        hipLaunchKernelGGL(pick(aux && aux->force_big, count, sh, mesh), dim3(a.n_blocks), dim3(kBlock), 0, stream, b);
+        hipLaunchKernelGGL(pick(aux && aux->force_big, count, sh, mesh), dim3(a.n_blocks * 4u), dim3(kWG), 0, stream, b);
     } else {
         // heavy blocks (the first *n_heavy ranks of the cost-sorted order) on the big-window kernel, on a second
         // stream so that both launches share the GPU; the main stream joins it before anything else runs
@@ -175,12 +185,12 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
         e = hipEventRecord(aux->fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(aux->aux, aux->fork, 0);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(pick(true, count, sh, mesh), dim3(std::min(aux->heavy_cap, a.n_blocks)), dim3(kBlock), 0,
+            hipLaunchKernelGGL(pick(true, count, sh, mesh), dim3(std::min(aux->heavy_cap, a.n_blocks * 4u)), dim3(kWG), 0,
                                aux->aux, h);
             e = hipEventRecord(aux->join, aux->aux);
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(pick(false, count, sh, mesh), dim3(a.n_blocks), dim3(kBlock), 0, stream, n);
+            hipLaunchKernelGGL(pick(false, count, sh, mesh), dim3(a.n_blocks * 4u), dim3(kWG), 0, stream, n);
             e = hipStreamWaitEvent(stream, aux->join, 0);
         }
     }
