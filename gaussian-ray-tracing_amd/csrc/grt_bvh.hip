@@ -226,7 +226,12 @@ __global__ void k_iota_neg(const uint32_t* __restrict__ cost, uint32_t n, uint32
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = ~cost[i]; // ascending sort of ~cost == descending cost
+    // descending cost, coarsely: only the leading 3 bits of the cost enter the key, and the radix sort is stable, so
+    // units of similar cost stay in screen order — neighbours that share BVH nodes are then launched together (and,
+    // through the XCD-aware rank map of the kernels, on the same XCD / L2)
+    const uint32_t c = cost[i];
+    const uint32_t sh = c > 7u ? (uint32_t)(29 - __clz((int)c)) : 0u;
+    keys[i] = ~((c >> sh) << sh);
     vals[i] = i;
 }
 

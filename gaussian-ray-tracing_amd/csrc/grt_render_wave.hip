@@ -96,7 +96,7 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
                 const uint32_t idx = (first + j) * 4u;
                 const float4 r0 = sload4(a.rec, idx), r1 = sload4(a.rec, idx + 1), r2 = sload4(a.rec, idx + 2),
                              r3 = sload4(a.rec, idx + 3);
-                if (COUNT) c.fetches++;
+                if (COUNT) c.fetches += 4; // 64-B record, in 16-B units
                 const f3 mu = mk3(r0.x, r0.y, r0.z);
                 m33 A;
                 A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
@@ -128,7 +128,7 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
             const uint32_t idx = cur * 4u;
             const float4 q0 = sload4(a.nodes, idx), q1 = sload4(a.nodes, idx + 1), q2 = sload4(a.nodes, idx + 2),
                          q3 = sload4(a.nodes, idx + 3);
-            if (COUNT) { c.fetches++; if (alive) c.node_visits++; }
+            if (COUNT) { c.fetches += 4; if (alive) c.node_visits++; }
             float n0, f0, n1, f1;
             box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
             box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);

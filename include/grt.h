@@ -95,8 +95,9 @@ typedef struct {
     uint64_t rounds;      /* k-buffer traversal rounds (traceGPs equivalents) */
     uint64_t node_visits; /* BVH node box tests by live rays (Gaussian BVH + mesh BVH) */
     uint64_t proxy_tests; /* exact icosahedron-slab tests executed */
-    uint64_t rec_fetches; /* 64-B node/proxy record fetches at the granularity the kernel loads them:
-                             per lane in the per-lane kernel, per wave (scalar load) in the wave kernel */
+    uint64_t rec_fetches; /* BVH node / proxy record bytes fetched by the wave-cooperative kernels, in 16-B units, at
+                             the granularity they are loaded (one scalar load per wave): streaming kernel — a 4-wide
+                             node = 8, a proxy record + its eye record = 5; round-based wave kernel — a 64-B record = 4 */
 } grt_counters;
 
 typedef struct {

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects the profiles this directory holds (run on the GPU box from the repo root):
+#   profiles/collect.sh <tag>        e.g.  profiles/collect.sh r01b
+# 1. rocprofv3 --kernel-trace --stats of the default bench command      -> <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json
+# 2. separate --pmc passes (no trace domains combined with them): FETCH_SIZE | WRITE_SIZE | TCC hit/miss/EA | SQ (2 passes)
+#    of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`       -> <tag>_counters.json (via summarise.py)
+set -e
+TAG=${1:-rXX}
+R=$PWD
+export TMPDIR=/tmp
+O=$R/gpurun_out/collect_$TAG
+rm -rf $O; mkdir -p $O
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_WAIT_INST_ANY" \
+         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc$i -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc$i.log 2>&1
+  echo "pass $i done: $C"
+done
+cd $R
+python3 profiles/summarise.py $O $TAG

@@ -59,3 +59,29 @@ def test_split_launch_with_mesh_and_tiles():
     img = tiles8.reshape(4, 6, 32, 32, 3).permute(0, 2, 1, 3, 4).reshape(128, 192, 3)
     assert (img == ref8).all()
     tr.close()
+
+
+def test_eye_records_follow_the_camera_and_the_scene():
+    """The streaming kernel caches per-eye proxy records in the context: a moved camera, a camera moved back, and a
+    new scene on the same tracer must each give the oracle's frame (a stale cache would not)."""
+    import copy
+    from common import to_oracle_params
+    from test_gpu_parity import compare as compare_frames
+    acts, p, sc, op, center = make_scene(21, 8000, 128, 96, scale_boost=0.4)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    cams = []
+    for eye in ((0.0, 0.0, 3.0), (1.5, 0.4, 2.2), (0.0, 0.0, 3.0), (-0.7, -1.1, 2.6)):
+        q = grt.default_params(128, 96, center, eye=np.float32(eye))
+        cams.append(q)
+        u8, f32 = tr.render(q, want_f32=True)
+        ref_u8, ref_f32, _ = sc.render(to_oracle_params(q))
+        compare_frames(f32, ref_f32, u8, ref_u8)
+    # same eye, different scene: the records must be rebuilt by the upload
+    acts2, p2, sc2, op2, _ = make_scene(22, 6000, 128, 96, scale_boost=0.4)
+    tr.upload(acts2)
+    q = copy.copy(cams[-1])
+    u8, f32 = tr.render(q, want_f32=True)
+    ref_u8, ref_f32, _ = sc2.render(to_oracle_params(q))
+    compare_frames(f32, ref_f32, u8, ref_u8)
+    tr.close()
