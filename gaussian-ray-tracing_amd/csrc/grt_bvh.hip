@@ -231,7 +231,11 @@ __global__ void k_iota_neg(const uint32_t* __restrict__ cost, uint32_t n, uint32
     // through the XCD-aware rank map of the kernels, on the same XCD / L2)
     const uint32_t c = cost[i];
     const uint32_t sh = c > 7u ? (uint32_t)(29 - __clz((int)c)) : 0u;
+#ifdef GRT_EXACT_COST_SORT
+    keys[i] = ~c;
+#else
     keys[i] = ~((c >> sh) << sh);
+#endif
     vals[i] = i;
 }
 
