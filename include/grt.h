@@ -118,13 +118,15 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                (per-lane otherwise),
                                3 = same as 0 */,
        GRT_OPT_LEAF_MAX = 3 /* max primitives per BVH leaf, 1..8 (default 4); applies to the next build */,
-       GRT_OPT_SWIZZLE = 4  /* screen blocks per XCD run in the workgroup->block map (0 = identity) */,
-       GRT_OPT_FEEDBACK = 5 /* 1 (default): launch blocks heaviest-first using the previous frame's per-block cost; in
-                               launches of <= 3072 blocks (a multi-GPU rank's share of a frame) additionally run the
-                               heaviest blocks on the 32-slot big-window kernel on a second stream (shorter critical
-                               path).  3: heaviest-first only.  5: big-window split always.  0: off */,
-       GRT_OPT_HEAVY_THRESHOLD_X2 = 6 /* a block is heavy when its cost exceeds value/2 x the median cost (default 4) */,
-       GRT_OPT_HEAVY_CAP_DIV = 7      /* at most n_blocks / value blocks go to the big-window kernel (default 8) */ };
+       GRT_OPT_SWIZZLE = 4  /* XCD-aware launch order: runs of value 16x16 screen blocks (4 x value 8x8 tiles of the
+                               streaming kernel) go to one XCD, i.e. one L2 (0 = identity; default 2) */,
+       GRT_OPT_FEEDBACK = 5 /* 1 (default): launch the scheduling units (8x8 tiles for the streaming kernel, 16x16 blocks
+                               for the others) heaviest-first using the previous frame's per-unit cost; in launches of
+                               <= 3072 blocks (a multi-GPU rank's share of a frame) additionally run the heaviest tiles on
+                               the 32-slot big-window kernel on a second stream (shorter critical path).
+                               3: heaviest-first only.  5: big-window split always.  0: off */,
+       GRT_OPT_HEAVY_THRESHOLD_X2 = 6 /* a unit is heavy when its cost exceeds value/2 x the median cost (default 4) */,
+       GRT_OPT_HEAVY_CAP_DIV = 7      /* at most 1/value of the units go to the big-window kernel (default 8) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
