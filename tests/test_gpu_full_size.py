@@ -1,0 +1,93 @@
+"""Parity at BASELINE.json's full sizes (C3: 1 M Gaussians at 1920x1080; C5: 3 M at 3840x2160 fisheye) through
+properties that do not need the oracle to render the whole frame:
+  * kernel independence: the streaming kernel, the round-based wave kernel and (on a window) the per-lane kernel are
+    three separate implementations of the traversal and must agree bit for bit;
+  * shard independence: the 8-rank tile split, un-permuted, is the full frame;
+  * schedule independence: frames launched in cost order (scheduling feedback, big-window split) are unchanged;
+  * the oracle itself on sampled windows, including the frame's heaviest tiles (radiance within 1e-4, 8-bit within 1).
+"""
+import numpy as np
+import pytest
+import torch
+
+import grt
+import tiles
+from common import make_scene
+from test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_full_size_properties_and_oracle_windows():
+    W, H = 1920, 1080
+    acts, p, sc, op, _ = make_scene(3, 1_000_000, W, H)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    u8, f32 = tr.render(p, want_f32=True)
+    u8, f32 = u8.clone(), f32.clone()
+    assert int(u8.sum().item()) > 0
+    # ---- kernel independence ----
+    tr.set_option(grt.OPT_KERNEL, 2)
+    a8, af = tr.render(p, want_f32=True)
+    assert (a8 == u8).all() and (af == f32).all()
+    tr.set_option(grt.OPT_KERNEL, 1)
+    win = (640, 536, 832, 664)  # around the heaviest tiles of this frame
+    w8 = torch.zeros_like(u8); wf = torch.zeros_like(f32)
+    tr.render(p, window=win, out_u8=w8, out_f32=wf)
+    x0, y0, x1, y1 = win
+    assert (w8[y0:y1, x0:x1] == u8[y0:y1, x0:x1]).all() and (wf[y0:y1, x0:x1] == f32[y0:y1, x0:x1]).all()
+    tr.set_option(grt.OPT_KERNEL, 0)
+    # ---- schedule independence: steady-state frames (heaviest-first), forced big-window split ----
+    for fb in (1, 5):
+        tr.set_option(grt.OPT_FEEDBACK, fb)
+        for _ in range(3):
+            a8, af = tr.render(p, want_f32=True)
+        assert (a8 == u8).all() and (af == f32).all(), fb
+    tr.set_option(grt.OPT_FEEDBACK, 1)
+    # ---- shard independence: 8 ranks ----
+    world = 8
+    tx, ty = tiles.grid(W, H, 32)
+    gathered = []
+    for rank in range(world):
+        _, _, cnt, max_cnt = tiles.my_tiles(tx * ty, world, rank)
+        buf = torch.zeros((max_cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+        for _ in range(2):  # second frame runs in cost order
+            tr.render_tiles(p, 32, 32, rank, world, cnt, out_u8=buf)
+        gathered.append(buf)
+    assert (tiles.assemble(gathered, W, H, 32) == u8).all()
+    # ---- the oracle on sampled windows ----
+    windows = [(720, 600, 728, 608), (712, 600, 720, 608), (888, 264, 896, 272), (1048, 872, 1056, 880),
+               (0, 0, 32, 32), (944, 524, 976, 556), (1888, 1048, 1920, 1080), (300, 900, 332, 916)]
+    hits = 0
+    for (x0, y0, x1, y1) in windows:
+        ref_u8, ref_f32, rc = sc.render(op, window=(x0, y0, x1, y1), threads=8)
+        compare(f32[y0:y1, x0:x1], ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1])
+        hits += rc["hit_evals"]
+    assert hits > 20000  # the sample is not empty space
+    tr.close()
+    sc.close()
+
+
+def test_c5_full_size_fisheye_kernel_and_shard_independence():
+    W, H = 3840, 2160
+    acts, p, sc, op, _ = make_scene(5, 3_000_000, W, H, fisheye=True)
+    sc.close()
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    u8, _ = tr.render(p)
+    u8 = u8.clone()
+    assert (u8[:8, :8] == 0).all()  # fisheye: r > 1 is black
+    tr.set_option(grt.OPT_KERNEL, 2)
+    a8, _ = tr.render(p)
+    assert (a8 == u8).all()
+    tr.set_option(grt.OPT_KERNEL, 0)
+    world = 8
+    tx, ty = tiles.grid(W, H, 32)
+    gathered = []
+    for rank in range(world):
+        _, _, cnt, max_cnt = tiles.my_tiles(tx * ty, world, rank)
+        buf = torch.zeros((max_cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+        tr.render_tiles(p, 32, 32, rank, world, cnt, out_u8=buf)
+        gathered.append(buf)
+    assert (tiles.assemble(gathered, W, H, 32) == u8).all()
+    tr.close()
