@@ -228,8 +228,7 @@ void grt_destroy(grt_ctx* c)
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_erec);
     (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
-    (void)hipFree(c->d_sort_tmp);
+    (void)hipFree(c->d_cost); (void)hipFree(c->d_order);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -477,27 +476,22 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
                              ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
     if (c->cost_cap < n_units) {
-        (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_skeys); (void)hipFree(c->d_svals);
-        c->d_cost = c->d_order = c->d_skeys = c->d_svals = nullptr;
+        (void)hipFree(c->d_cost); (void)hipFree(c->d_order);
+        c->d_cost = c->d_order = nullptr;
         c->cost_cap = 0;
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * n_units));
-        CHK(c, hipMalloc(&c->d_skeys, sizeof(uint32_t) * 2 * n_units));
-        CHK(c, hipMalloc(&c->d_svals, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     if (same) {
-        int rc = sort_blocks_by_cost(c->d_cost, c->d_order, c->d_skeys, c->d_svals, &c->d_sort_tmp, &c->sort_tmp_bytes,
-                                     n_units, s, &c->err);
+        const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
+        int rc = order_units_by_cost(c->d_cost, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
+                                     (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
-        if (c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u)) {
-            count_heavy_blocks(c->d_cost, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
-                               (uint32_t)c->opt_heavy_thr_x2, c->d_n_heavy, s);
-            a.n_heavy = c->d_n_heavy;
-        }
+        if (split) a.n_heavy = c->d_n_heavy;
     }
     CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
     a.cost = c->d_cost;

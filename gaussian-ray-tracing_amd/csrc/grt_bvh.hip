@@ -221,44 +221,68 @@ __global__ void k_refit_pass(float4* __restrict__ nodes, uint32_t* __restrict__ 
     level[i] = pass;
 }
 
-__global__ void k_iota_neg(const uint32_t* __restrict__ cost, uint32_t n, uint32_t* __restrict__ keys,
-                           uint32_t* __restrict__ vals)
+// ---- launch order of the scheduling units: heaviest first, by cost CLASS ----
+// A class keeps the leading 3 bits of the cost (124 classes); inside a class the units stay in (approximately) screen
+// order, so neighbours that share BVH nodes are launched together and — through the XCD-aware rank map of the kernels —
+// on one XCD / L2.  One workgroup does it all (histogram, scan, scatter in chunks of 1024 units in order): ~10 us for
+// 32 k units, instead of a general radix/merge sort's eight small launches in front of every frame.  The same kernel
+// counts the heavy units (cost above thr_x2/2 x the median, at class granularity) for the split launch.
+__device__ __forceinline__ uint32_t cost_class(uint32_t c)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // descending cost, coarsely: only the leading 3 bits of the cost enter the key, and the radix sort is stable, so
-    // units of similar cost stay in screen order — neighbours that share BVH nodes are then launched together (and,
-    // through the XCD-aware rank map of the kernels, on the same XCD / L2)
-    const uint32_t c = cost[i];
-    const uint32_t sh = c > 7u ? (uint32_t)(29 - __clz((int)c)) : 0u;
-#ifdef GRT_EXACT_COST_SORT
-    keys[i] = ~c;
-#else
-    keys[i] = ~((c >> sh) << sh);
-#endif
-    vals[i] = i;
+    if (c < 8u) return c;
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    return (e - 1u) * 4u + ((c >> (e - 2u)) & 3u);
+}
+__device__ __forceinline__ uint32_t cost_class_floor(uint32_t k)
+{
+    if (k < 8u) return k;
+    if (k >= 124u) return 0xFFFFFFFFu; // classes above the largest 32-bit cost: never populated
+    const uint32_t e = k / 4u + 1u, m = k & 3u;
+    return (4u | m) << (e - 2u);
 }
 
-int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
-                        void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err)
+__global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict__ cost, uint32_t n,
+                                                     uint32_t* __restrict__ order, uint32_t cap, uint32_t thr_x2,
+                                                     uint32_t* __restrict__ n_heavy)
+{
+    __shared__ uint32_t hist[128], cursor[128];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 128u) hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost[i])], 1u); // bucket 0 = heaviest
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t acc = 0, bmed = 127u;
+        bool found = false;
+        for (uint32_t b = 0; b < 128u; b++) {
+            cursor[b] = acc;
+            acc += hist[b];
+            if (!found && acc > n / 2u) { bmed = b; found = true; }
+        }
+        if (n_heavy) {
+            const uint32_t thr = (cost_class_floor(127u - bmed) * thr_x2) >> 1;
+            uint32_t bh = 0;
+            while (bh < 128u && cost_class_floor(127u - bh) > thr) bh++;
+            const uint32_t heavy = bh < 128u ? cursor[bh] : n;
+            *n_heavy = heavy < cap ? heavy : cap;
+        }
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + tid;
+        if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost[i])], 1u)] = i;
+        __syncthreads();
+    }
+}
+
+int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
+                        uint32_t* d_n_heavy, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
-    hipLaunchKernelGGL(k_iota_neg, dim3((n + 255) / 256), dim3(256), 0, stream, d_cost, n, d_scratch_keys, d_scratch_vals);
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, d_scratch_keys, d_scratch_keys + n, d_scratch_vals, d_order,
-                                             (size_t)n, 0u, 32u, stream);
-    if (e == hipSuccess && need > *tmp_bytes) {
-        if (*d_tmp) (void)hipFree(*d_tmp);
-        *d_tmp = nullptr;
-        *tmp_bytes = 0;
-        e = hipMalloc(d_tmp, need);
-        if (e == hipSuccess) *tmp_bytes = need;
-    }
-    if (e == hipSuccess)
-        e = rocprim::radix_sort_pairs(*d_tmp, need, d_scratch_keys, d_scratch_keys + n, d_scratch_vals, d_order, (size_t)n,
-                                      0u, 32u, stream);
+    hipLaunchKernelGGL(k_cost_order, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, heavy_cap, thr_x2, d_n_heavy);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        if (err) *err = std::string("sort_blocks_by_cost: ") + hipGetErrorString(e);
+        if (err) *err = std::string("order_units_by_cost: ") + hipGetErrorString(e);
         return GRT_ERR_HIP;
     }
     return GRT_OK;
@@ -308,27 +332,6 @@ __global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restr
 #undef GRT_WB
     w[6] = make_float4(__uint_as_float(ref[0]), __uint_as_float(ref[1]), __uint_as_float(ref[2]), __uint_as_float(ref[3]));
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-__global__ void k_count_heavy(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ order, uint32_t n,
-                              uint32_t cap, uint32_t thr_x2, uint32_t* __restrict__ out)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    const uint32_t median = cost[order[n / 2]];
-    const uint32_t thr = (median * thr_x2) >> 1;
-    uint32_t lo = 0, hi = n < cap ? n : cap;              // order is sorted by cost, descending
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (cost[order[mid]] > thr) lo = mid + 1; else hi = mid;
-    }
-    *out = lo;
-}
-
-int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t thr_x2,
-                       uint32_t* d_n_heavy, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(64), 0, stream, d_cost, d_order, n, cap, thr_x2, d_n_heavy);
-    return GRT_OK;
 }
 
 void free_bvh(DevBvh* b)

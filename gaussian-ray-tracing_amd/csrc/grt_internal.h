@@ -103,11 +103,10 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
 constexpr int kNumCounters = 7;
 // number of leading blocks of the cost-sorted order whose cost exceeds 2.5x the median (capped): they run on the
 // big-window kernel
-int count_heavy_blocks(const uint32_t* d_cost, const uint32_t* d_order, uint32_t n, uint32_t cap, uint32_t thr_x2,
-                       uint32_t* d_n_heavy, hipStream_t stream);
 // heaviest-first block order for the next frame: order = argsort(cost, descending)
-int sort_blocks_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t* d_scratch_keys, uint32_t* d_scratch_vals,
-                        void** d_tmp, size_t* tmp_bytes, uint32_t n, hipStream_t stream, std::string* err);
+// launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
+int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
+                        uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
 
 }  // namespace grt
 
@@ -146,9 +145,7 @@ struct grt_ctx {
     bool have_timing = false;
     // frame-to-frame scheduling feedback (grt_api.hip: do_launch)
     int opt_feedback = 1;
-    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_skeys = nullptr, *d_svals = nullptr;
-    void* d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    uint32_t *d_cost = nullptr, *d_order = nullptr;
     uint32_t cost_cap = 0;
     bool cost_valid = false;
     // wavefront buffers (allocated on first mesh frame)
