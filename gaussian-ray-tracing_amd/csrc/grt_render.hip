@@ -17,23 +17,29 @@
 namespace grt {
 
 constexpr int K = 7;           // MaxNumHitPerTrace, shaders/tracer.cuh:11
+#ifndef GRT_BOUNCE_K
+#define GRT_BOUNCE_K 10
+#endif
+constexpr int kBounceK = GRT_BOUNCE_K; // k-buffer of the bounce stage: same hits in the same order, fewer re-traversal rounds
 constexpr int kBlock = 256;
 
 struct Cnt {
     uint32_t rays = 0, segments = 0, hit_evals = 0, rounds = 0, node_visits = 0, proxy_tests = 0, iters = 0;
 };
 
+template <int KK>
 struct KBuf {
-    uint64_t key[K];
-    float alpha[K];
+    uint64_t key[KK];
+    float alpha[KK];
 };
 
-__device__ __forceinline__ void kbuf_insert(KBuf& kb, uint64_t key, float alpha)
+template <int KK>
+__device__ __forceinline__ void kbuf_insert(KBuf<KK>& kb, uint64_t key, float alpha)
 {
     // same effect as the 7 compare-and-swap steps of __anyhit__anyhit (shaders/tracer.cu:124-146)
-    if (key >= kb.key[K - 1]) return;
+    if (key >= kb.key[KK - 1]) return;
 #pragma unroll
-    for (int i = 0; i < K; i++) {
+    for (int i = 0; i < KK; i++) {
         if (key < kb.key[i]) {
             const uint64_t tk = kb.key[i];
             const float ta = kb.alpha[i];
@@ -46,12 +52,12 @@ __device__ __forceinline__ void kbuf_insert(KBuf& kb, uint64_t key, float alpha)
 }
 
 // one k-nearest round: traceGPs + __anyhit__ (shaders/tracer.cuh:289-326, shaders/tracer.cu:136-153)
-template <bool COUNT>
+template <bool COUNT, int KK>
 __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
-                                          const rayinv& ri, uint64_t last_key, float t_hi, KBuf& kb, Cnt& c)
+                                          const rayinv& ri, uint64_t last_key, float t_hi, KBuf<KK>& kb, Cnt& c)
 {
 #pragma unroll
-    for (int i = 0; i < K; i++) {
+    for (int i = 0; i < KK; i++) {
         kb.key[i] = kKeyInvalid;
         kb.alpha[i] = 0.0f;
     }
@@ -91,7 +97,7 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
                             const uint64_t k = mk_key(tx, id, 1);
                             if (k > last_key) kbuf_insert(kb, k, alpha);
                         }
-                        if (kb.key[K - 1] != kKeyInvalid) bound = key_t(kb.key[K - 1]);
+                        if (kb.key[KK - 1] != kKeyInvalid) bound = key_t(kb.key[KK - 1]);
                     }
                 }
             }
@@ -124,7 +130,7 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
 }
 
 // trace() — shaders/tracer.cuh:328-373
-template <bool COUNT>
+template <bool COUNT, int KK>
 __device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
                                                 float t_min, float t_max, float& density, f3& radiance, Cnt& c)
 {
@@ -139,13 +145,13 @@ __device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* _
     uint64_t last_key = mk_key(lastT + epsT, 0x7FFFFFFFu, 1);
     const float t_hi = t_max + epsT;
     const float minT = a.p.minTransmittance;
-    KBuf kb;
+    KBuf<KK> kb;
     while (lastT <= t_max && T > minT) {
-        gps_round<COUNT>(a, stk, o, d, ri, last_key, t_hi, kb, c);
+        gps_round<COUNT, KK>(a, stk, o, d, ri, last_key, t_hi, kb, c);
         if (COUNT) c.rounds++;
         if (kb.key[0] == kKeyInvalid) break;
 #pragma unroll
-        for (int i = 0; i < K; i++) {
+        for (int i = 0; i < KK; i++) {
             if (kb.key[i] != kKeyInvalid && T > minT) {
                 if (COUNT) c.hit_evals++;
                 lastT = fmaxf(key_t(kb.key[i]), lastT);
@@ -164,8 +170,8 @@ __device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* _
                 }
             }
         }
-        if (kb.key[K - 1] == kKeyInvalid) break; // fewer than K hits left: the next round would be empty
-        last_key = kb.key[K - 1];
+        if (kb.key[KK - 1] == kKeyInvalid) break; // fewer than KK hits left: the next round would be empty
+        last_key = kb.key[KK - 1];
     }
     density = 1.0f - T;
 }
@@ -282,7 +288,7 @@ __device__ __forceinline__ void mesh_shade(const RenderArgs& a, const MeshHit& m
 }
 
 // __raygen__raygeneration bounce loop (shaders/tracer.cu:58-106), resumable from a RayState
-template <bool COUNT>
+template <bool COUNT, int KK>
 __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, RayState st, Cnt& c)
 {
     f3 curO = st.curO, curD = st.curD;
@@ -298,7 +304,7 @@ __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restric
         mesh_shade(a, mh, ray_o, ray_d, state, seg_tmax, normal, curO, curD, numBounces);
         // the single Gaussian segment of this iteration (one call site keeps the kernel small)
         f3 rad;
-        trace_gaussians<COUNT>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c);
+        trace_gaussians<COUNT, KK>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c);
         const float alpha = density;
         if (state == Terminate) { // renderNormal, shaders/tracer.cuh:417-428
             accumColor = add3(accumColor, rad);
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
         st.accumAlpha = q2.y; st.blocking = q2.z; st.density = q2.w;
         st.numBounces = __float_as_uint(q3.x); st.timeout = __float_as_uint(q3.y);
         const size_t out_idx = (size_t)__float_as_uint(q3.z) | ((size_t)__float_as_uint(q3.w) << 32);
-        const f3 col = shade_ray<COUNT>(a, stk, st, c);
+        const f3 col = shade_ray<COUNT, kBounceK>(a, stk, st, c);
         if (a.outf) {
             a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
         }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
         if (i < a.n_rays) {
             const float* r = a.rays + i * 6;
             if (COUNT) c.rays++;
-            const f3 col = shade_ray<COUNT>(a, stk, fresh_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])), c);
+            const f3 col = shade_ray<COUNT, K>(a, stk, fresh_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])), c);
             a.outf[i * 3] = col.x; a.outf[i * 3 + 1] = col.y; a.outf[i * 3 + 2] = col.z;
         }
     } else {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
             else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
             if (have_ray) {
                 if (COUNT) c.rays++;
-                col = shade_ray<COUNT>(a, stk, fresh_ray(mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]), dir), c);
+                col = shade_ray<COUNT, K>(a, stk, fresh_ray(mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]), dir), c);
             }
         }
         if (write) {
