@@ -1,22 +1,26 @@
 // grt_render_stream.hip — single-pass, wave-cooperative "streaming" render kernel (gfx950).
 //
-// Same contract and per-lane arithmetic as grt_render_wave.hip (one wave64 = one 8x8 pixel tile, scalar
-// record fetches, bit-identical results), but the k = 7 re-traversal rounds of trace()
-// (shaders/tracer.cuh:341-369) are replaced by ONE front-to-back pass:
-//   * the wave expands the LBVH BEST-FIRST: the frontier (unexpanded subtrees) lives in wave registers —
-//     slot i is lane i of (lambda, ref) VGPR pairs, 128 slots — keyed by lambda = the smallest box-entry
-//     distance over the lanes that want the subtree; pop = DPP min-reduction + ballot + v_readlane;
-//   * when a subtree with key lambda is popped, no unseen hit of any lane can have t < lambda, so every
-//     buffered hit event with t < lambda is FINAL and is composited immediately, in key order
-//     (t, particle id, entry<exit) — exactly the order the rounds would have produced;
-//   * each lane buffers PARTICLES, not hits: a slot holds (current key, other t, alpha); compositing an entry
-//     event re-keys the slot to its exit event.  7 slots cover a window of ~14 hits;
-//   * when the frontier is full, children go to a depth-first wave-register stack instead (popped before
-//     any frontier entry, finality bound unchanged), so the frontier can never overflow;
-//   * a lane whose window overflows records the smallest key it had to drop (`cutoff`), keeps compositing
-//     below it, and — only if it still has transmittance left at the end of the pass — starts another
-//     pass from its last composited key (the reference's "next round", now the exception, not the rule);
+// Same contract and per-lane arithmetic as grt_render_wave.hip (bit-identical results), but one workgroup is ONE
+// wave64 = one 8x8 pixel tile, and the k = 7 re-traversal rounds of trace() (shaders/tracer.cuh:341-369) are replaced
+// by ONE front-to-back pass over the 4-wide view of the LBVH (grt_bvh.hip: k_widen):
+//   * records are fetched once per wave with scalar loads: a 128-B wide node, or a 64-B proxy record plus the 16-B
+//     per-eye record that holds what depends on the ray origin only (grt_api.hip: k_eye_records);
+//   * the wave expands the tree BEST-FIRST: the frontier (unexpanded subtrees) lives in wave registers — slot i is
+//     lane i of one (lambda, ref) VGPR pair, 64 slots — keyed by lambda = the smallest box-entry distance over the
+//     lanes that want the subtree; pop = DPP min-reduction + ballot + v_readlane.  A full frontier spills to a
+//     depth-first stack in LDS that is drained first (finality bound unchanged);
+//   * when a subtree with key lambda is popped, no unseen hit of any lane can have t < lambda, so every buffered hit
+//     event with t < lambda is FINAL and is composited immediately, in key order (t, particle id, entry<exit) —
+//     exactly the order the rounds would have produced;
+//   * each lane buffers PARTICLES, not hits: 12 sorted 64-bit keys in registers (payload: exit t and alpha in LDS
+//     cells named by the key's low bits); compositing an entry event re-keys the slot to its exit event.  The sorted
+//     insert / pop are generated inline assembly (gen_slots.py -> grt_slots_gen.inc);
+//   * a lane whose window overflows records the smallest key it had to drop (`cutoff`), keeps compositing below it,
+//     and — only if it still has transmittance left at the end of the pass — starts another pass from its last
+//     composited key (the reference's "next round", now the exception, not the rule);
 //   * lanes stop wanting subtrees once T <= minTransmittance, so the pass ends early for opaque tiles.
+// The body (grt_render_stream_body.inc) is instantiated twice: 12 slots at 4 waves/SIMD, and 32 slots at 2 waves/SIMD
+// for the tiles the scheduling feedback marks as heavy.  DESIGN.md §5.2 has the measurements behind each choice.
 //
 // Style note: the per-lane slot file and the wave-level frontier are plain local scalars driven by macros
 // (no structs passed by reference, no loop-indexed arrays): that is what keeps all of it in registers —
@@ -132,9 +136,6 @@ __device__ __forceinline__ v2f unpack2(uint64_t u)
 #define GRT_DEF_WAVES 4
 #endif
 #define GRT_WAVES GRT_DEF_WAVES
-#ifndef GRT_FBANKS
-#define GRT_FBANKS 1
-#endif
 #define GRT_KERNEL_NAME k_render_stream
 #include "grt_render_stream_body.inc"
 #undef GRT_KS
