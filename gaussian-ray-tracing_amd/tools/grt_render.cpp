@@ -2,7 +2,7 @@
 // (src/main.cpp:9-131) on a display-less MI355X: same flags -p/--ply, --width, --height and the same
 // defaults (src/main.cpp:62-66: ../data/train.ply, 1280x720), the same call sequence
 // (tracer.setSize -> initializeOptix -> camera init (src/gui.cpp:50-67) -> updateCamera -> render),
-// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm --bench N.
+// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png --bench N.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -15,11 +15,67 @@
 
 #include "../host/GaussianTracer.h"
 
+// Minimal PNG writer (8-bit RGB, stored deflate blocks: no compression library needed; CRC-32 and Adler-32 per the
+// PNG / zlib specifications)
+static void write_png(const std::string& path, const unsigned char* rgb_top_down, unsigned int w, unsigned int h)
+{
+    static unsigned int crc_table[256];
+    if (!crc_table[1])
+        for (unsigned int n = 0; n < 256; n++) {
+            unsigned int c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+    auto be32 = [](std::vector<unsigned char>& v, unsigned int x) {
+        v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16)); v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+    };
+    std::ofstream f(path, std::ios::binary);
+    auto chunk = [&](const char* type, const std::vector<unsigned char>& data) {
+        std::vector<unsigned char> buf;
+        be32(buf, (unsigned int)data.size());
+        buf.insert(buf.end(), type, type + 4);
+        buf.insert(buf.end(), data.begin(), data.end());
+        unsigned int c = 0xFFFFFFFFu;
+        for (size_t i = 4; i < buf.size(); i++) c = crc_table[(c ^ buf[i]) & 0xFFu] ^ (c >> 8);
+        be32(buf, c ^ 0xFFFFFFFFu);
+        f.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)buf.size());
+    };
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    f.write(reinterpret_cast<const char*>(sig), 8);
+    std::vector<unsigned char> ihdr;
+    be32(ihdr, w); be32(ihdr, h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); // 8-bit, RGB
+    chunk("IHDR", ihdr);
+    std::vector<unsigned char> raw; // filter byte 0 + row
+    raw.reserve((size_t)h * (w * 3 + 1));
+    for (unsigned int y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb_top_down + (size_t)y * w * 3, rgb_top_down + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};
+    unsigned int a1 = 1, a2 = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        for (size_t i = 0; i < n; i++) {
+            a1 = (a1 + raw[pos + i]) % 65521u;
+            a2 = (a2 + a1) % 65521u;
+        }
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    }
+    be32(z, (a2 << 16) | a1);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+}
+
 static void usage()
 {
     std::puts("usage: grt_render [-p|--ply scene.ply] [--width W] [--height H] [--fisheye] [--type mirror|normal|glass]\n"
               "                  [--sh-degree 0..3] [--plane] [--sphere] [--obj mesh.obj] [--bounces N]\n"
-              "                  [--eye x y z] [--fov deg] [--out frame.ppm] [--bench N]");
+              "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png] [--bench N]");
 }
 
 int main(int argc, char** argv)
@@ -93,10 +149,16 @@ int main(int argc, char** argv)
         }
         if (!out.empty()) {
             const std::vector<unsigned char>& rgb = output_buffer.download();
-            std::ofstream f(out, std::ios::binary);
-            f << "P6\n" << width << " " << height << "\n255\n";
+            std::vector<unsigned char> top_down((size_t)width * height * 3);
             for (unsigned int y = 0; y < height; y++) // row 0 is the bottom of the window (src/Display.cpp:13,184)
-                f.write(reinterpret_cast<const char*>(rgb.data() + (size_t)(height - 1 - y) * width * 3), (std::streamsize)width * 3);
+                memcpy(top_down.data() + (size_t)y * width * 3, rgb.data() + (size_t)(height - 1 - y) * width * 3, (size_t)width * 3);
+            if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
+                write_png(out, top_down.data(), width, height);
+            } else {
+                std::ofstream f(out, std::ios::binary);
+                f << "P6\n" << width << " " << height << "\n255\n";
+                f.write(reinterpret_cast<const char*>(top_down.data()), (std::streamsize)top_down.size());
+            }
             std::cout << "wrote " << out << "\n";
         }
     } catch (const std::exception& e) {

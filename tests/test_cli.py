@@ -21,6 +21,27 @@ def _read_ppm(path):
         return np.frombuffer(f.read(), np.uint8).reshape(h, w, 3)[::-1]  # file is top-down, frame row 0 = bottom
 
 
+def _read_png(path):
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(typ + data) & 0xFFFFFFFF)
+        if typ == b"IHDR":
+            w, h, depth, colour = struct.unpack(">IIBB", data[:10])
+            assert (depth, colour) == (8, 2)
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 3 + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 3)[::-1]  # file is top-down, frame row 0 = bottom
+
+
 def _scene(tmp_path, seed=12, n=3000):
     raw = grt.synth_scene(seed, n)
     raw["scale"] = raw["scale"] + np.float32(0.6)
@@ -53,6 +74,11 @@ def test_cli_frame_matches_oracle(tmp_path):
     ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
     got = _read_ppm(out)
     assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and cnt["hit_evals"] > 160 * 96
+    # the same frame as PNG (stored-deflate writer in the CLI): decodes to the same bytes
+    png = str(tmp_path / "f.png")
+    r = subprocess.run([CLI, "-p", ply, "--width", "160", "--height", "96", "--out", png], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (_read_png(png) == got).all()
 
 
 @pytest.mark.gpu
