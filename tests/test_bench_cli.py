@@ -1,0 +1,43 @@
+"""bench.py end to end on the smallest workload: the JSON contract of the default run, and the multi-slot
+(frames in flight) step of a multi-GPU rank, exercised on one GPU through --emulate-ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "C1", "--steps", "4", "--warmup", "1", *args],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and d["config"]["frames_in_flight"] == 1
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+    assert d["value"] > 5 * cb["value"]
+
+
+def test_bench_frames_in_flight_on_an_emulated_rank():
+    d = _run("--no-cpu-baseline", "--emulate-ranks", "2")
+    c = d["config"]
+    assert c["frames_in_flight"] == 4 and c["latency_ms_per_frame"] > 0 and "rank 1 of 2" in c["emulated_ranks"]
+    assert d["value"] > 0 and d["kernel_ms"] > 0
