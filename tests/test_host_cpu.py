@@ -158,3 +158,12 @@ def test_ply_with_fewer_sh_bands_reads_missing_f_rest_as_zero(tmp_path):
     assert (back["f_rest"][:, 9:] == 0).all()
     for k in ("pos", "f_dc", "opacity", "scale", "rot"):
         assert back[k].tobytes() == raw[k].tobytes()
+
+
+def test_generated_slot_macros_are_current():
+    """csrc/grt_slots_gen.inc is generated: the committed file must be what gen_slots.py prints."""
+    import subprocess
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussian-ray-tracing_amd", "csrc")
+    out = subprocess.run([sys.executable, os.path.join(d, "gen_slots.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(d, "grt_slots_gen.inc")).read()
