@@ -298,3 +298,27 @@ def test_feedback_scheduling_does_not_change_pixels(tr):
         assert (a8 == b8).all() and (af == bf).all()
     ref_u8, ref_f32, _ = sc.render(op)
     compare(af, ref_f32, a8, ref_u8)
+
+
+def test_coincident_gaussians_deep_overlap(tr):
+    """Collisions: 600 Gaussians share one centre exactly (identical Morton codes, a tall LBVH) with different sizes
+    and low opacity, inside a random cloud — several hundred proxies overlap along the central rays, far more than any
+    window holds, so the streaming kernel must make progress pass after pass and still composite in exact key order."""
+    raw = grt.synth_scene(31, 1500)
+    raw["pos"][:600] = np.float32([0.05, -0.02, 0.1])
+    raw["scale"][:600] = np.log(np.float32(0.02) + np.float32(0.0006) * np.arange(600, dtype=np.float32))[:, None]
+    raw["opacity"][:600] = np.float32(-1.5)  # sigmoid -> 0.18: the rays go deep before they saturate
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    p = grt.default_params(72, 64, center)
+    sc = O.Scene(acts_to_particles(acts))
+    tr.upload(acts)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p))
+    compare(f32, ref_f32, u8, ref_u8)
+    assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
+    assert rc["hit_evals"] > 20 * rc["rays"]
+    sc.close()
