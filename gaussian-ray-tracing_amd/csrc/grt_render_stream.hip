@@ -83,6 +83,35 @@ __device__ __forceinline__ float wave_min(float v)
 #endif
 }
 
+// four independent wave minima in lockstep: the DPP steps of different reductions interleave, so the two wait states a
+// DPP operand needs after its producer are filled with useful work instead of s_nop
+__device__ __forceinline__ void wave_min4(float a, float b, float c, float d, float& ra, float& rb, float& rc, float& rd)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t x0 = __float_as_uint(a), x1 = __float_as_uint(b), x2 = __float_as_uint(c), x3 = __float_as_uint(d);
+#define GRT_DPP_STEP(CTRL)                                                                                 \
+    {                                                                                                      \
+        const uint32_t y0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x0, CTRL, 0xF, 0xF, true);       \
+        const uint32_t y1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x1, CTRL, 0xF, 0xF, true);       \
+        const uint32_t y2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x2, CTRL, 0xF, 0xF, true);       \
+        const uint32_t y3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x3, CTRL, 0xF, 0xF, true);       \
+        x0 = min(x0, y0); x1 = min(x1, y1); x2 = min(x2, y2); x3 = min(x3, y3);                            \
+    }
+    GRT_DPP_STEP(0xB1)  // quad_perm [1,0,3,2]
+    GRT_DPP_STEP(0x4E)  // quad_perm [2,3,0,1]
+    GRT_DPP_STEP(0x141) // row_half_mirror
+    GRT_DPP_STEP(0x140) // row_mirror
+#undef GRT_DPP_STEP
+#define GRT_ROWS(x)                                                                                        \
+    __uint_as_float(min(min((uint32_t)__builtin_amdgcn_readlane((int)x, 0), (uint32_t)__builtin_amdgcn_readlane((int)x, 16)), \
+                        min((uint32_t)__builtin_amdgcn_readlane((int)x, 32), (uint32_t)__builtin_amdgcn_readlane((int)x, 48))))
+    ra = GRT_ROWS(x0); rb = GRT_ROWS(x1); rc = GRT_ROWS(x2); rd = GRT_ROWS(x3);
+#undef GRT_ROWS
+#else
+    ra = a; rb = b; rc = c; rd = d;
+#endif
+}
+
 // votes straight on the lane mask (the __any/__ballot wrappers go through an int and cost two extra VALU ops)
 __device__ __forceinline__ uint64_t wave_ballot(bool p)
 {
