@@ -1,0 +1,39 @@
+"""A viewer-like run at full size: 120 frames of the 1 M-Gaussian scene at 1920x1080 with a camera that orbits and dives
+into the cloud (pinhole, a few wide-angle and fisheye frames), scheduling feedback on — every 20th frame is compared
+bit for bit with the independent round-based kernel and, on random windows, with the oracle."""
+import numpy as np
+import pytest
+
+import grt
+from common import make_scene, to_oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def test_moving_camera_soak():
+    W, H = 1920, 1080
+    acts, _, sc, _, center = make_scene(3, 1_000_000, W, H)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tw = grt.Tracer(0)
+    tw.set_option(grt.OPT_KERNEL, 2)
+    tw.upload(acts)
+    rng = np.random.default_rng(7)
+    n = 120
+    for i in range(n):
+        ang = 2 * np.pi * i / n
+        r = 3.0 - 2.6 * abs(np.sin(3 * ang))  # from outside (3.0) to inside the cloud (0.4)
+        eye = np.float32([r * np.sin(ang), 0.6 * np.sin(2 * ang), r * np.cos(ang)])
+        fisheye = i % 37 == 0
+        p = grt.default_params(W, H, center, eye=eye, fovy=60.0 if i % 50 else 100.0, fisheye=fisheye)
+        u8, f32 = tr.render(p, want_f32=True)
+        if i % 20 == 0:
+            a8, af = tw.render(p, want_f32=True)
+            assert (a8 == u8).all() and (af == f32).all(), i
+            if not fisheye:  # fisheye pixels may flip a near-tie against glibc trig (covered by test_fisheye*)
+                for _ in range(2):
+                    x0 = int(rng.integers(0, W - 16)); y0 = int(rng.integers(0, H - 16))
+                    _, rf32, _ = sc.render(to_oracle_params(p), window=(x0, y0, x0 + 16, y0 + 16), threads=8)
+                    d = np.abs(f32[y0:y0 + 16, x0:x0 + 16].cpu().numpy() - rf32[y0:y0 + 16, x0:x0 + 16]).max()
+                    assert d <= 1e-4, (i, x0, y0, d)
+    tr.close(); tw.close(); sc.close()
