@@ -246,7 +246,11 @@ int grt_set_option(grt_ctx* c, int option, int value)
 {
     if (!c) return GRT_ERR_INVALID;
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
-    else if (option == GRT_OPT_KERNEL) c->opt_kernel = value;
+    else if (option == GRT_OPT_KERNEL) {
+        if (value < 0 || value > GRT_KERNEL_MAX) { c->err = "GRT_OPT_KERNEL must be 0.." + std::to_string(GRT_KERNEL_MAX); return GRT_ERR_INVALID; }
+        c->opt_kernel = value;
+        c->cost_valid = false; // scheduling units differ between kernels
+    }
     else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : ((value & 2) ? 0 : 2); c->cost_valid = false; }
     else if (option == GRT_OPT_HEAVY_THRESHOLD_X2) { c->opt_heavy_thr_x2 = std::max(2, value); }
     else if (option == GRT_OPT_HEAVY_CAP_DIV) { c->opt_heavy_cap_div = std::max(1, value); }
@@ -299,6 +303,7 @@ int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
 int grt_build_bvh(grt_ctx* c, float alpha_min)
 {
     if (!c) return GRT_ERR_INVALID;
+    if (!(alpha_min > 0.0f)) { c->err = "grt_build_bvh: alpha_min must be > 0"; return GRT_ERR_INVALID; }
     CHK(c, hipSetDevice(c->device));
     c->built = false;
     c->alpha_min = alpha_min;
@@ -385,26 +390,33 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
     if (nf == 0) return GRT_OK;
     float* d_verts = nullptr;
     float4 *d_lo = nullptr, *d_hi = nullptr;
-    CHK(c, hipMalloc(&d_verts, (size_t)nv * 3 * sizeof(float)));
-    CHK(c, hipMalloc(&c->d_vnormals, (size_t)nv * 3 * sizeof(float)));
-    CHK(c, hipMalloc(&c->d_faces, (size_t)nf * 3 * sizeof(uint32_t)));
-    CHK(c, hipMalloc(&d_lo, (size_t)nf * sizeof(float4)));
-    CHK(c, hipMalloc(&d_hi, (size_t)nf * sizeof(float4)));
-    CHK(c, hipMemcpyAsync(d_verts, v.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipMemcpyAsync(c->d_vnormals, nrm.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    CHK(c, hipMemcpyAsync(c->d_faces, f.data(), (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
-    int rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, &c->mbvh, c->stream, &c->err);
+    int rc = GRT_OK;
+    hipError_t e = hipSuccess;
+    // every failure falls through to the common clean-up below (temporaries freed, mesh state reset)
+    if ((e = hipMalloc(&d_verts, (size_t)nv * 3 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&c->d_vnormals, (size_t)nv * 3 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&c->d_faces, (size_t)nf * 3 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&d_lo, (size_t)nf * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(&d_hi, (size_t)nf * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(&c->d_tri, (size_t)nf * 3 * sizeof(float4))) != hipSuccess ||
+        (e = hipMemcpyAsync(d_verts, v.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->d_vnormals, nrm.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->d_faces, f.data(), (size_t)nf * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream)) != hipSuccess) {
+        c->err = std::string("grt_set_meshes: ") + hipGetErrorString(e);
+        rc = GRT_ERR_HIP;
+    }
     if (rc == GRT_OK) {
-        hipError_t e = hipMalloc(&c->d_tri, (size_t)nf * 3 * sizeof(float4));
-        if (e != hipSuccess) { c->err = std::string("grt_set_meshes: hipMalloc: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+        hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
+        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, &c->mbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK) {
         hipLaunchKernelGGL(k_gather_tris, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
                            c->mbvh.order, nf, c->d_tri);
-        hipError_t e = hipStreamSynchronize(c->stream);
+        e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("grt_set_meshes: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+    } else {
+        (void)hipStreamSynchronize(c->stream); // host vectors are borrowed by the async copies
     }
     (void)hipFree(d_verts); (void)hipFree(d_lo); (void)hipFree(d_hi);
     if (rc != GRT_OK) { free_meshes(c); return rc; }
@@ -508,7 +520,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         // the streaming kernel runs one 8x8 tile (one wave) per workgroup and is scheduled per tile; the other
         // kernels per 16x16 block (same test as launch_render)
         const uint32_t h = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
-        const bool stream_kernel = c->opt_kernel != 1 && c->opt_kernel != 2 && a.mode != 2 && h <= 120;
+        const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
         int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks);
         if (rcf != GRT_OK) return rcf;
     }
@@ -621,7 +633,7 @@ int grt_get_counters(grt_ctx* c, grt_counters* out)
     unsigned long long h[kNumCounters];
     CHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->rays = h[0]; out->segments = h[1]; out->hit_evals = h[2]; out->rounds = h[3];
-    out->node_visits = h[4]; out->proxy_tests = h[5]; out->rec_fetches = h[6];
+    out->node_visits = h[4]; out->proxy_tests = h[5]; out->rec_fetches = h[6]; out->stall_exits = h[7];
     return GRT_OK;
 }
 

@@ -400,9 +400,12 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         out->lo[k] = m ? ord2f(h_bounds[k]) : 0.f;
         out->hi[k] = m ? ord2f(h_bounds[3 + k]) : 0.f;
     }
-    if (m == 0) goto done;
-    if (m <= leaf_max) { // the whole scene is one leaf range
-        out->root_ref = kLeafBit | ((m - 1u) << 28);
+    if (m <= leaf_max) { // empty, or the whole scene is one leaf range: no node arrays (drop stale ones of an earlier build)
+        if (out->wnodes) (void)hipFree(out->wnodes);
+        if (out->nodes) (void)hipFree(out->nodes);
+        out->wnodes = out->nodes = nullptr;
+        out->cap_nodes = 0;
+        if (m) out->root_ref = kLeafBit | ((m - 1u) << 28);
         goto done;
     }
     if (out->cap_nodes < (size_t)(m - 1)) {

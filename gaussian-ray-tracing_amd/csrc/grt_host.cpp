@@ -230,15 +230,40 @@ int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f_dc, flo
     for (size_t k = 0; k < names.size(); k++) {
         for (size_t j = 0; j < h.props.size(); j++)
             if (h.props[j].name == names[k]) idx[k] = (int)j;
-        // Exports trained at SH degree < 3 carry fewer f_rest_* columns: the missing
-        // coefficients are zero.  Every other property is required, as the reference's getProperty() is.
+        // Every property but f_rest_* is required, as the reference's getProperty() is.
         const bool is_rest = names[k].compare(0, 7, "f_rest_") == 0;
         if (idx[k] < 0 && !is_rest) { g_host_err = "PLY: missing property '" + names[k] + "'"; return GRT_ERR_IO; }
+    }
+    // Exports trained at SH degree L < 3 carry 3*K f_rest_* columns, K = (L+1)^2 - 1, CHANNEL-MAJOR with stride K
+    // (f_rest_0..K-1 = red, K..2K-1 = green, 2K..3K-1 = blue).  The activation reads the
+    // degree-3 layout (stride 15, src/GaussianData.cpp:113-128), so column c*K+j goes to slot c*15+j and the bands the
+    // file does not have stay zero.  Any other column count is not a 3DGS export: rejected.
+    size_t n_rest = 0;
+    while (n_rest < 45 && idx[6 + n_rest] >= 0) n_rest++;
+    for (size_t q = n_rest; q < 45; q++)
+        if (idx[6 + q] >= 0) { g_host_err = "PLY: f_rest_* columns are not contiguous from f_rest_0"; return GRT_ERR_IO; }
+    if (n_rest != 0 && n_rest != 9 && n_rest != 24 && n_rest != 45) {
+        g_host_err = "PLY: " + std::to_string(n_rest) + " f_rest_* columns (expected 0, 9, 24 or 45)";
+        return GRT_ERR_IO;
+    }
+    std::vector<int> rest_slot(45, -1); // destination slot of source column q
+    {
+        const size_t K = n_rest / 3;
+        for (size_t q = 0; q < n_rest; q++) rest_slot[q] = (int)((q / K) * 15 + (q % K));
+        // columns the file lacks still have to be zeroed: give each missing name one of the unused slots
+        std::vector<bool> used(45, false);
+        for (size_t q = 0; q < n_rest; q++) used[rest_slot[q]] = true;
+        size_t next = 0;
+        for (size_t q = n_rest; q < 45; q++) {
+            while (used[next]) next++;
+            rest_slot[q] = (int)next;
+            used[next] = true;
+        }
     }
     auto store = [&](uint64_t i, size_t k, float v) {
         if (k < 3) pos[i * 3 + k] = v;
         else if (k < 6) f_dc[i * 3 + (k - 3)] = v;
-        else if (k < 51) f_rest[i * 45 + (k - 6)] = v;
+        else if (k < 51) f_rest[i * 45 + rest_slot[k - 6]] = v;
         else if (k == 51) opacity_logit[i] = v;
         else if (k < 55) log_scale[i * 3 + (k - 52)] = v;
         else rot[i * 4 + (k - 55)] = v;

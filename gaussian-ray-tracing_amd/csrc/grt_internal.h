@@ -100,7 +100,16 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
                          std::string* err);
-constexpr int kNumCounters = 7;
+constexpr int kNumCounters = 8;
+// GRT_OPT_KERNEL values: 0 auto, 1 per-lane, 2 round-based wave, 3 = 0, 4 big-window streaming (testing)
+constexpr int GRT_KERNEL_MAX = 4;
+// true when the launch runs on the streaming wave kernel (alone, or as stage 2 of the mesh wavefront pipeline): its
+// scheduling units are 8x8 tiles (4 per 16x16 block).  ONE predicate for do_launch (sizes order[] / cost[]) and
+// launch_render (picks the kernel), so the two can never disagree about the unit of order[].
+inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
+{
+    return variant != 1 && variant != 2 && mode != 2 && stack_depth <= 120u;
+}
 // number of leading blocks of the cost-sorted order whose cost exceeds 2.5x the median (capped): they run on the
 // big-window kernel
 // heaviest-first block order for the next frame: order = argsort(cost, descending)

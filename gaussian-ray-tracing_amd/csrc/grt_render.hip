@@ -539,11 +539,16 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     if (a.n_blocks == 0) return GRT_OK;
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
     const bool wave_ok = (a.mroot == kNoRoot) && (a.mode != 2) && (stack_depth <= 120);
+    const bool streaming = uses_stream_kernel(kernel_variant, a.mode, stack_depth); // same test as do_launch's
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
-    if ((kernel_variant == 0 || kernel_variant == 3 || kernel_variant == 4) && wave_ok) return launch_render_stream(a, count, false, stream, aux, err);
+    if (streaming && a.mroot == kNoRoot) return launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
-    if (kernel_variant != 1 && kernel_variant != 2 && a.mroot != kNoRoot && a.mode != 2 && stack_depth <= 120 && a.prec && a.queue && a.qcount) {
+    if (streaming) {
+        if (!a.prec || !a.queue || !a.qcount) {
+            if (err) *err = "wavefront pipeline: continuation buffers missing";
+            return GRT_ERR_INVALID;
+        }
         if (lds > 160 * 1024) {
             if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
             return GRT_ERR_LIMIT;

@@ -27,7 +27,7 @@ class Params(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests",
-                                          "rec_fetches")]
+                                          "rec_fetches", "stall_exits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

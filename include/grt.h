@@ -98,6 +98,8 @@ typedef struct {
     uint64_t rec_fetches; /* BVH node / proxy record bytes fetched by the wave-cooperative kernels, in 16-B units, at
                              the granularity they are loaded (one scalar load per wave): streaming kernel — a 4-wide
                              node = 8, a proxy record + its eye record = 5; round-based wave kernel — a 64-B record = 4 */
+    uint64_t stall_exits; /* rays the streaming kernel gave up on with transmittance left because two passes in a row
+                             composited nothing (must be 0: a non-zero value means a pixel is missing hits) */
 } grt_counters;
 
 typedef struct {

@@ -322,3 +322,50 @@ def test_coincident_gaussians_deep_overlap(tr):
     assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
     assert rc["hit_evals"] > 20 * rc["rays"]
     sc.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 4])
+@pytest.mark.parametrize("n", [1, 2, 4])
+def test_tiny_scene_in_a_fresh_context(kernel, n):
+    """<= leaf_max hittable proxies: the LBVH root is a leaf range and there is NO node array.  A fresh context (no
+    stale buffers of an earlier, larger scene) must render it through grt_render on the streaming kernels."""
+    t = grt.Tracer(0)
+    try:
+        t.set_option(grt.OPT_KERNEL, kernel)
+        raw = grt.synth_scene(4, n); raw["pos"][:] *= 0.2; raw["scale"][:] = -1.5; raw["opacity"][:] = 2.0
+        acts = grt.activate(raw)
+        t.upload(acts)
+        assert t.bvh_info()["n_nodes"] == n - 1
+        p = grt.default_params(48, 40, (0, 0, 0))
+        u8, f32 = t.render(p, want_f32=True)
+        sc = O.Scene(acts_to_particles(acts))
+        ref_u8, ref_f32, rc = sc.render(to_oracle_params(p))
+        compare(f32, ref_f32, u8, ref_u8)
+        assert rc["hit_evals"] > 0
+        # all but <= 4 particles below alpha_min, after a larger scene in the same context
+        raw = grt.synth_scene(5, 3000); t.upload(grt.activate(raw))
+        t.render(p)
+        raw = grt.synth_scene(5, 300); raw["opacity"][3:] = -9.0; raw["opacity"][:3] = 3.0; raw["scale"][:3] = -1.2
+        raw["pos"][:3] *= 0.1
+        acts = grt.activate(raw)
+        t.upload(acts)
+        assert t.bvh_info()["n_proxies"] == 3
+        u8, f32 = t.render(p, want_f32=True)
+        sc = O.Scene(acts_to_particles(acts))
+        ref_u8, ref_f32, rc = sc.render(to_oracle_params(p))
+        compare(f32, ref_f32, u8, ref_u8)
+    finally:
+        t.close()
+
+
+def test_option_values_are_validated():
+    t = grt.Tracer(0)
+    try:
+        for bad in (-1, 99):
+            with pytest.raises(grt.GrtError, match="GRT_OPT_KERNEL"):
+                t.set_option(grt.OPT_KERNEL, bad)
+        raw = grt.synth_scene(4, 10)
+        with pytest.raises(grt.GrtError, match="alpha_min"):
+            t.upload(grt.activate(raw), alpha_min=0.0)
+    finally:
+        t.close()

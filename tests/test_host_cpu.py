@@ -142,22 +142,50 @@ def test_oracle_mesh_bvh_equals_bruteforce(mesh_type):
     assert ca["segments"] > ca["rays"] or mesh_type == grt.NORMAL  # secondary segments exist
 
 
-def test_ply_with_fewer_sh_bands_reads_missing_f_rest_as_zero(tmp_path):
-    """3DGS exports trained at SH degree 1 carry only f_rest_0..8."""
-    raw = grt.synth_scene(6, 40)
-    names = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{k}" for k in range(9)] + ["opacity"] + \
-            [f"scale_{k}" for k in range(3)] + [f"rot_{k}" for k in range(4)]
-    cols = np.concatenate([raw["pos"], raw["f_dc"], raw["f_rest"][:, :9], raw["opacity"][:, None], raw["scale"], raw["rot"]], 1)
-    q = str(tmp_path / "deg1.ply")
-    with open(q, "wb") as f:
-        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex 40\n" +
-                 "".join(f"property float {n}\n" for n in names) + "end_header\n").encode())
+def _write_ply_with_rest(path, raw, rest_cols):
+    n = len(raw["pos"])
+    k = rest_cols.shape[1]
+    names = ["x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{j}" for j in range(k)] + ["opacity"] + \
+            [f"scale_{j}" for j in range(3)] + [f"rot_{j}" for j in range(4)]
+    cols = np.concatenate([raw["pos"], raw["f_dc"], rest_cols, raw["opacity"][:, None], raw["scale"], raw["rot"]], 1)
+    with open(path, "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {n}\n" +
+                 "".join(f"property float {m}\n" for m in names) + "end_header\n").encode())
         f.write(np.ascontiguousarray(cols, np.float32).tobytes())
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_ply_with_fewer_sh_bands_maps_channels(tmp_path, deg):
+    """3DGS exports trained at SH degree L < 3 carry 3K f_rest columns, K = (L+1)^2-1, channel-major with stride K
+    (SURVEY §8(f) rank 4).  Column c*K+j must land where the degree-3 layout keeps channel c, coefficient j
+    (slot c*15+j), so that GaussianData.cpp:113-128's sh[k] = (f_rest[k-1], f_rest[14+k], f_rest[29+k]) sees the
+    right colour channel; the bands the file lacks are zero."""
+    raw = grt.synth_scene(6, 40)
+    K = (deg + 1) ** 2 - 1
+    rest = np.random.default_rng(deg).normal(size=(40, 3 * K)).astype(np.float32)
+    q = str(tmp_path / f"deg{deg}.ply")
+    _write_ply_with_rest(q, raw, rest)
     back = grt.read_ply(q)
-    assert back["f_rest"][:, :9].tobytes() == np.ascontiguousarray(raw["f_rest"][:, :9]).tobytes()
-    assert (back["f_rest"][:, 9:] == 0).all()
+    want = np.zeros((40, 45), np.float32)
+    for c in range(3):
+        want[:, c * 15:c * 15 + K] = rest[:, c * K:(c + 1) * K]
+    assert back["f_rest"].tobytes() == want.tobytes()
     for k in ("pos", "f_dc", "opacity", "scale", "rot"):
         assert back[k].tobytes() == raw[k].tobytes()
+    # through the activation: sh[1+j] of a particle = (R_j, G_j, B_j) of the file
+    acts = grt.activate(back)
+    for j in range(K):
+        assert (acts["sh"][:, 1 + j, 0] == rest[:, j]).all() and (acts["sh"][:, 1 + j, 1] == rest[:, K + j]).all() \
+            and (acts["sh"][:, 1 + j, 2] == rest[:, 2 * K + j]).all()
+    assert (acts["sh"][:, 1 + K:] == 0).all()
+
+
+def test_ply_with_odd_f_rest_count_is_rejected(tmp_path):
+    raw = grt.synth_scene(6, 8)
+    q = str(tmp_path / "bad.ply")
+    _write_ply_with_rest(q, raw, np.zeros((8, 10), np.float32))
+    with pytest.raises(grt.GrtError, match="f_rest"):
+        grt.read_ply(q)
 
 
 def test_generated_slot_macros_are_current():
