@@ -258,6 +258,10 @@ int grt_set_option(grt_ctx* c, int option, int value)
         if (value < 0) { c->err = "GRT_OPT_SWIZZLE must be >= 0"; return GRT_ERR_INVALID; }
         c->opt_swizzle = value;
     }
+    else if (option == GRT_OPT_TILE_READY_MIN) { c->opt_tile_ready = std::min(64, std::max(1, value)); }
+    else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
+    else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
+    else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
         if (value < 1 || value > (int)kLeafMaxPrims) { c->err = "GRT_OPT_LEAF_MAX must be 1..8"; return GRT_ERR_INVALID; }
         c->opt_leaf_max = value; // takes effect at the next grt_build_bvh / grt_set_meshes
@@ -330,7 +334,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, &c->gbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, &c->gbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
@@ -360,7 +364,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     c->have_timing = false;
     c->cost_valid = false;
     c->erec_valid = false;
-    if (rc == GRT_OK) c->built = true;
+    if (rc == GRT_OK) { c->built = true; c->built_leaf_max = c->opt_leaf_max; }
     return rc;
 }
 
@@ -407,7 +411,7 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
     }
     if (rc == GRT_OK) {
         hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, &c->mbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, false, &c->mbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK) {
         hipLaunchKernelGGL(k_gather_tris, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
@@ -455,6 +459,8 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     a->rec = c->d_rec;
     a->nodes = c->gbvh.nodes;
     a->wnodes = c->gbvh.wnodes;
+    a->qnodes = c->gbvh.qnodes;
+    a->pbox = c->gbvh.pbox;
     a->root_ref = c->gbvh.root_ref;
     a->n_prox = c->gbvh.n_prims;
     a->color0 = c->d_color0;
@@ -557,7 +563,13 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
     aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_units / (uint32_t)c->opt_heavy_cap_div) : 0u; // in scheduling units
     aux.force_big = c->opt_kernel == 4;
-    int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, s, &aux, &c->err);
+    const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, c->built_leaf_max);
+    if (tile_kernel) { a.n_heavy = nullptr; aux.heavy_cap = 0; } // no big-window split on the tile kernel
+    a.tile_ready_min = (uint32_t)c->opt_tile_ready;
+    a.tile_band = (float)c->opt_tile_band / 1024.0f;
+    a.tile_look = (float)c->opt_tile_look / 1024.0f;
+    a.tile_reserve = (uint32_t)c->opt_tile_reserve;
+    int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);
     return rc;

@@ -334,15 +334,41 @@ __global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restr
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Per-child layout of the same 4-wide tree for the tile kernel (one lane tests one child box: 2 x 16-B loads).
+__global__ void k_qwiden(const float4* __restrict__ wn, int m, float4* __restrict__ qn)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1) return;
+    const float4* w = wn + (size_t)i * 8;
+    const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
+    // wide record: per child (lo.x lo.y | hi.x hi.y | lo.z hi.z)
+    float4* q = qn + (size_t)i * 8;
+    q[0] = make_float4(w0.x, w0.y, w1.x, w6.x); q[1] = make_float4(w0.z, w0.w, w1.y, 0.0f);
+    q[2] = make_float4(w1.z, w1.w, w2.z, w6.y); q[3] = make_float4(w2.x, w2.y, w2.w, 0.0f);
+    q[4] = make_float4(w3.x, w3.y, w4.x, w6.z); q[5] = make_float4(w3.z, w3.w, w4.y, 0.0f);
+    q[6] = make_float4(w4.z, w4.w, w5.z, w6.w); q[7] = make_float4(w5.x, w5.y, w5.w, 0.0f);
+}
+
+__global__ void k_pbox(const float4* __restrict__ lb_lo, const float4* __restrict__ lb_hi, uint32_t m,
+                       float4* __restrict__ pbox)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    pbox[(size_t)j * 2] = lb_lo[j];
+    pbox[(size_t)j * 2 + 1] = lb_hi[j];
+}
+
 void free_bvh(DevBvh* b)
 {
+    if (b->qnodes) (void)hipFree(b->qnodes);
+    if (b->pbox) (void)hipFree(b->pbox);
     if (b->wnodes) (void)hipFree(b->wnodes);
     if (b->nodes) (void)hipFree(b->nodes);
     if (b->order) (void)hipFree(b->order);
     *b = DevBvh();
 }
 
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, DevBvh* out,
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, DevBvh* out,
                hipStream_t stream, std::string* err)
 {
     uint2* d_range = nullptr;
@@ -400,12 +426,26 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         out->lo[k] = m ? ord2f(h_bounds[k]) : 0.f;
         out->hi[k] = m ? ord2f(h_bounds[3 + k]) : 0.f;
     }
+    if (out->qnodes) (void)hipFree(out->qnodes);
+    if (out->pbox) (void)hipFree(out->pbox);
+    out->qnodes = out->pbox = nullptr;
+    if (m) {
+        HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
+        HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, out->order, m, d_lblo,
+                           d_lbhi);
+        if (want_quad) {
+            HIPCHK(hipMalloc(&out->pbox, sizeof(float4) * 2 * (size_t)m + 256));
+            hipLaunchKernelGGL(k_pbox, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lblo, d_lbhi, m, out->pbox);
+        }
+    }
     if (m <= leaf_max) { // empty, or the whole scene is one leaf range: no node arrays (drop stale ones of an earlier build)
         if (out->wnodes) (void)hipFree(out->wnodes);
         if (out->nodes) (void)hipFree(out->nodes);
         out->wnodes = out->nodes = nullptr;
         out->cap_nodes = 0;
         if (m) out->root_ref = kLeafBit | ((m - 1u) << 28);
+        HIPCHK(hipStreamSynchronize(stream));
         goto done;
     }
     if (out->cap_nodes < (size_t)(m - 1)) {
@@ -415,13 +455,9 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         HIPCHK(hipMalloc(&out->nodes, sizeof(float4) * 4 * (size_t)(m - 1)));
         out->cap_nodes = m - 1;
     }
-    HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
-    HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
     HIPCHK(hipMalloc(&d_level, sizeof(uint32_t) * (m - 1)));
     HIPCHK(hipMalloc(&d_range, sizeof(uint2) * (m - 1)));
     HIPCHK(hipMemsetAsync(d_level, 0, sizeof(uint32_t) * (m - 1), stream));
-    hipLaunchKernelGGL(k_leaf_boxes, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, out->order, m, d_lblo,
-                       d_lbhi);
     hipLaunchKernelGGL(k_hierarchy, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, d_keys2, (int)m, out->nodes, d_range);
     {
         uint32_t pass = 0, root_level = 0;
@@ -451,6 +487,10 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     if (leaf_max > 1)
         hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
     hipLaunchKernelGGL(k_widen, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->wnodes);
+    if (want_quad) {
+        HIPCHK(hipMalloc(&out->qnodes, sizeof(float4) * 8 * (size_t)(m - 1) + 256));
+        hipLaunchKernelGGL(k_qwiden, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->wnodes, (int)m, out->qnodes);
+    }
     HIPCHK(hipStreamSynchronize(stream));
 done:
     HIPCHK(hipGetLastError());

@@ -30,6 +30,11 @@ struct DevBvh {
     float4* wnodes = nullptr;  // [(n_prims-1) * 8] 4-wide view of the same tree (two binary levels per record):
                                //   24 floats = 4 child boxes, each (lo.x lo.y | hi.x hi.y | lo.z hi.z),
                                //   W6 = 4 child refs, W7 pad; an unused child has ref kNoRoot
+    float4* qnodes = nullptr;  // [(n_prims-1) * 8] the same 4-wide tree laid out per CHILD for the tile kernel
+                               //   (grt_render_tile.hip: one lane tests one child box): child c of node i at
+                               //   [i*8 + 2c] = (lo.xyz, ref bits), [i*8 + 2c + 1] = (hi.xyz, 0); unused child: ref kNoRoot
+    float4* pbox = nullptr;    // [n_prims * 2] box of every sorted primitive, (lo.xyz,0)(hi.xyz,0): what a leaf-range
+                               //   child expands to in the tile kernel (built only for the Gaussian BVH)
     uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
     uint32_t n_prims = 0;      // valid primitives (leaves)
     uint32_t height = 0;       // levels of internal nodes (bounds the traversal stack)
@@ -40,7 +45,8 @@ struct DevBvh {
 
 // Build an LBVH over n_in boxes (invalid primitives have lo.x > hi.x and are left out).
 // Returns GRT_OK or an error code (message in *err).
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, DevBvh* out,
+// want_quad: also build the per-child layout (qnodes, pbox) the tile kernel traverses.
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, DevBvh* out,
                hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
 
@@ -52,6 +58,8 @@ struct RenderArgs {
     const float4* erec;   // [n_prox] per-eye part of the proxy test, same order (k_eye_records); camera frames only
     const float4* nodes;
     const float4* wnodes; // 4-wide records (streaming kernel)
+    const float4* qnodes; // 4-wide records, one 32-B slot per child (tile kernel)
+    const float4* pbox;   // [n_prox*2] per-proxy boxes in sorted order (tile kernel)
     uint32_t root_ref;
     uint32_t n_prox;
     const float4* color0; // [n_particles] degree-0 radiance by ORIGINAL particle id
@@ -81,7 +89,12 @@ struct RenderArgs {
     uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
     const uint32_t* n_heavy; // device count of leading blocks of `order` that run on the big-window kernel
     uint32_t heavy_role;     // 0 = every block, 1 = only ranks < *n_heavy, 2 = only ranks >= *n_heavy
-    unsigned long long* counters; // 7 x u64 or nullptr
+    unsigned long long* counters; // kNumCounters x u64 or nullptr
+    // tile kernel tuning (grt_render_tile.hip)
+    uint32_t tile_ready_min; // lanes that must hold a final event before a compositing sweep starts
+    float tile_band;         // particles within F * (1 + band) of the front are tested in one batch
+    float tile_look;         // nodes within Fn * (1 + look) are expanded in one step
+    uint32_t tile_reserve;   // free frontier slots below which leaf steps are forced
     // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
     float4* prec;      // [n_blocks*256][3] primary mesh-hit records
     float4* queue;     // [n_blocks*256][4] compacted continuation rays
@@ -95,24 +108,27 @@ struct LaunchAux {
     uint32_t heavy_cap = 0; // grid of the big-window launch (0 = no split)
     bool force_big = false; // GRT_OPT_KERNEL = 4: every block on the big-window kernel (testing)
 };
-int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
-                  const LaunchAux* aux, std::string* err);
+int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, bool tile_kernel,
+                  hipStream_t stream, const LaunchAux* aux, std::string* err);
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
                          std::string* err);
+int launch_render_tile(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 8;
-// GRT_OPT_KERNEL values: 0 auto, 1 per-lane, 2 round-based wave, 3 = 0, 4 big-window streaming (testing)
-constexpr int GRT_KERNEL_MAX = 4;
-// true when the launch runs on the streaming wave kernel (alone, or as stage 2 of the mesh wavefront pipeline): its
-// scheduling units are 8x8 tiles (4 per 16x16 block).  ONE predicate for do_launch (sizes order[] / cost[]) and
-// launch_render (picks the kernel), so the two can never disagree about the unit of order[].
+// GRT_OPT_KERNEL values: 0 auto, 1 per-lane, 2 round-based wave, 3 streaming, 4 big-window streaming (testing), 5 tile
+constexpr int GRT_KERNEL_MAX = 5;
+// true when the launch runs on a wave-per-tile kernel (streaming or tile kernel; alone, or as stage 2 of the mesh
+// wavefront pipeline): its scheduling units are 8x8 tiles (4 per 16x16 block).  ONE predicate for do_launch (sizes
+// order[] / cost[]) and launch_render (picks the kernel), so the two can never disagree about the unit of order[].
 inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
 {
     return variant != 1 && variant != 2 && mode != 2 && stack_depth <= 120u;
 }
-// number of leading blocks of the cost-sorted order whose cost exceeds 2.5x the median (capped): they run on the
-// big-window kernel
-// heaviest-first block order for the next frame: order = argsort(cost, descending)
+// the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
+inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max)
+{
+    return uses_stream_kernel(variant, mode, stack_depth) && variant == 5 && built_leaf_max <= 4;
+}
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
                         uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
@@ -127,6 +143,8 @@ struct grt_ctx {
     int opt_kernel = 0;
     int opt_leaf_max = 4;
     int opt_swizzle = 2;
+    int opt_tile_ready = 16, opt_tile_band = 16, opt_tile_look = 32, opt_tile_reserve = 24; // band / look in 1/1024
+    int built_leaf_max = 4; // leaf_max of the current Gaussian BVH (the tile kernel expands ranges of <= 4)
     // uploaded attributes (original order)
     uint64_t n = 0;
     float *d_pos = nullptr, *d_scale = nullptr, *d_quat = nullptr, *d_opacity = nullptr, *d_sh = nullptr;

@@ -533,8 +533,8 @@ __global__ __launch_bounds__(kBlock) void k_render(const RenderArgs a)
     }
 }
 
-int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, hipStream_t stream,
-                  const LaunchAux* aux, std::string* err)
+int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t stack_depth, bool tile_kernel,
+                  hipStream_t stream, const LaunchAux* aux, std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
     const size_t lds = (size_t)kBlock * sizeof(uint32_t) * (stack_depth ? stack_depth : 1);
@@ -542,7 +542,8 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     const bool streaming = uses_stream_kernel(kernel_variant, a.mode, stack_depth); // same test as do_launch's
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
-    if (streaming && a.mroot == kNoRoot) return launch_render_stream(a, count, false, stream, aux, err);
+    if (streaming && a.mroot == kNoRoot)
+        return tile_kernel ? launch_render_tile(a, count, false, stream, err) : launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
     if (streaming) {
         if (!a.prec || !a.queue || !a.qcount) {
@@ -563,7 +564,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             return GRT_ERR_HIP;
         }
         hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
-        int rc = launch_render_stream(a, count, true, stream, aux, err);
+        int rc = tile_kernel ? launch_render_tile(a, count, true, stream, err) : launch_render_stream(a, count, true, stream, aux, err);
         if (rc != GRT_OK) return rc;
         RenderArgs b = a;
         b.order = nullptr;

@@ -118,7 +118,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                mesh frames, per-lane kernel for ray buffers),
                                1 = per-lane kernel everywhere, 2 = round-based wave kernel for camera rays without meshes
                                (per-lane otherwise),
-                               3 = same as 0 */,
+                               3 = streaming kernel, 4 = its 32-slot variant everywhere (testing),
+                               5 = tile kernel (grt_render_tile.hip: BVH culling per child box against the tile frustum) */,
        GRT_OPT_LEAF_MAX = 3 /* max primitives per BVH leaf, 1..8 (default 4); applies to the next build */,
        GRT_OPT_SWIZZLE = 4  /* XCD-aware launch order: runs of value 16x16 screen blocks (4 x value 8x8 tiles of the
                                streaming kernel) go to one XCD, i.e. one L2 (0 = identity; default 2) */,
@@ -128,7 +129,12 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                the 32-slot big-window kernel on a second stream (shorter critical path).
                                3: heaviest-first only.  5: big-window split always.  0: off */,
        GRT_OPT_HEAVY_THRESHOLD_X2 = 6 /* a unit is heavy when its cost exceeds value/2 x the median cost (default 4) */,
-       GRT_OPT_HEAVY_CAP_DIV = 7      /* at most 1/value of the units go to the big-window kernel (default 8) */ };
+       GRT_OPT_HEAVY_CAP_DIV = 7      /* at most 1/value of the units go to the big-window kernel (default 8) */,
+       /* tile kernel (GRT_OPT_KERNEL = 5) tuning; pixels never depend on these */
+       GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event before a compositing sweep starts, 1..64 (16) */,
+       GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (16) */,
+       GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (32) */,
+       GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
