@@ -143,7 +143,7 @@ struct grt_ctx {
     int opt_kernel = 0;
     int opt_leaf_max = 4;
     int opt_swizzle = 2;
-    int opt_tile_ready = 16, opt_tile_band = 16, opt_tile_look = 32, opt_tile_reserve = 24; // band / look in 1/1024
+    int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24; // band / look in 1/1024
     int built_leaf_max = 4; // leaf_max of the current Gaussian BVH (the tile kernel expands ranges of <= 4)
     // uploaded attributes (original order)
     uint64_t n = 0;

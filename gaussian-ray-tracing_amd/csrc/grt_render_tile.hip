@@ -44,6 +44,7 @@ constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of Rend
 constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kernel
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
 constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
+constexpr uint32_t kMaxIters = 1u << 21; // steps of one tile before the watchdog gives up (a heavy C3 tile takes ~2000)
 constexpr uint32_t kKeep = 40u;  // frontier entries kept in registers by a rebalance (the nearest ones)
 
 #ifndef GRT_TILE_WAVES
@@ -62,6 +63,8 @@ constexpr uint32_t kKeep = 40u;  // frontier entries kept in registers by a reba
 // pops, proxy_tests: exact tests executed, rec_fetches: leaf steps, stall_exits: frontier rebalances.
 #ifdef GRT_TILE_DIAG
 #define GRT_D(f, n) if (COUNT) w.f += (n);
+#elif defined(GRT_MARKS)
+#define GRT_D(f, n) asm volatile("; GRT_MARK " #f);
 #else
 #define GRT_D(f, n)
 #endif
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                  k10 = kKeyInvalid, k11 = kKeyInvalid;
         uint32_t pmask = 0; // payload cells in use
         uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
+        bool watchdog = false;
         const uint32_t ready_min = a.tile_ready_min; // lanes with a final event before a compositing sweep starts
 
         while (wave_any(alive)) { // one iteration = one front-to-back pass
@@ -400,7 +404,11 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     }
                 }
                 if (done) break;
-                ++iters;
+                if (++iters > kMaxIters) { // watchdog: never reached by design; a counted, visible failure beats a hung GPU
+                    c.stall_exits += alive ? 1u : 0u;
+                    watchdog = true;
+                    break;
+                }
 
                 // ---- one step: the entries at the front, four lanes each.  LEAF step: leaf ranges -> their particles'
                 //      boxes are culled here and the survivors slab-tested at once (lanes = rays).  NODE step: internal
@@ -422,11 +430,11 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     // legal; spilling children to the depth-first stack stalls the front)
                     const uint32_t nocc = (uint32_t)__popcll(wave_ballot(occ_l));
                     const bool crowded = (nocc > 64u - a.tile_reserve) && (Fr < INFINITY);
-                    leaf_step = (Fr <= Fn) || crowded;
-                    // leaf step: the ranges in front of every unexpanded node, within a narrow band behind the front (a wide
-                    // band would fill the windows with far events); node step: the nearest node and a look-ahead behind it
-                    const float tau = leaf_step ? (crowded ? Fr + Fr * a.tile_band : fminf(Fn, Fr + Fr * a.tile_band))
-                                                : (Fn + Fn * ((nocc > 32u) ? 0.0f : a.tile_look));
+                    // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
+                    // then the nearest ranges (within a band behind the nearest one) are tested together
+                    const float hz = F + F * a.tile_look;
+                    leaf_step = (Fr < INFINITY) && (!(Fn <= hz) || crowded);
+                    const float tau = leaf_step ? (Fr + Fr * a.tile_band) : fmaxf(hz, Fn);
                     const bool cand = occ_l && (rng_l == leaf_step);
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
                     // one node: a frontier full of internal nodes overflows to the depth-first stack)
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             stalls = progressed ? 0u : stalls + 1u;
             const bool again = alive && (cutoff != kKeyInvalid);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
-            alive = again && (stalls < 2u);
+            alive = again && (stalls < 2u) && !watchdog;
         }
         if (a.cost && lane == 0) atomicMax(&a.cost[unit], iters);
     }
