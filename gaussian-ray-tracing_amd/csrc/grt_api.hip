@@ -117,6 +117,30 @@ __global__ void k_eye_records(const float4* __restrict__ rec, uint32_t m, float 
     erec[j] = make_float4(o_g.x, o_g.y, o_g.z, proxy_sphere_cc(o_g, r0.w));
 }
 
+// Wide eye records for the tile kernel, 64 B: the same (o_g, cc) plus the ten slab projections of o_g
+// (slab_project, grt_device.h) that the exact proxy test otherwise forms on every lane from wave-uniform inputs:
+//   (o_g.x o_g.y o_g.z cc) (a0 a1 a2 a3) (a4 a5 a6 a7) (a8 a9 0 0)
+__global__ void k_eye_records_wide(const float4* __restrict__ rec, uint32_t m, float ex, float ey, float ez,
+                                   float4* __restrict__ erec)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const float4 r0 = rec[(size_t)j * 4], r1 = rec[(size_t)j * 4 + 1], r2 = rec[(size_t)j * 4 + 2],
+                 r3 = rec[(size_t)j * 4 + 3];
+    m33 A;
+    A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+    A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+    A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+    const f3 o_g = matvec(A, sub3(mk3(ex, ey, ez), mk3(r0.x, r0.y, r0.z)));
+    float pa[10];
+    slab_project(o_g, pa);
+    float4* e = erec + (size_t)j * 4;
+    e[0] = make_float4(o_g.x, o_g.y, o_g.z, proxy_sphere_cc(o_g, r0.w));
+    e[1] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    e[2] = make_float4(pa[4], pa[5], pa[6], pa[7]);
+    e[3] = make_float4(pa[8], pa[9], 0.0f, 0.0f);
+}
+
 // degree-0 radiance max(0.5 + SH_C0 * sh[0], 0) (shaders/tracer.cuh:223,263), by original id
 __global__ void k_color0(const float* __restrict__ sh, uint32_t n, float4* __restrict__ color0)
 {
@@ -227,9 +251,11 @@ void grt_destroy(grt_ctx* c)
     free_bvh(&c->gbvh);
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_erec);
+    (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
+    (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     (void)hipFree(c->d_n_heavy);
@@ -261,6 +287,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_TILE_READY_MIN) { c->opt_tile_ready = std::min(64, std::max(1, value)); }
     else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
     else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
+    else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
         if (value < 1 || value > (int)kLeafMaxPrims) { c->err = "GRT_OPT_LEAF_MAX must be 1..8"; return GRT_ERR_INVALID; }
@@ -551,13 +578,27 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     if (a.mode != 2 && c->gbvh.n_prims && c->d_erec && c->opt_kernel != 1 && c->opt_kernel != 2) {
         // streaming kernel on camera rays: refresh the eye records when the eye moved (part of the timed frame)
         const uint32_t m = c->gbvh.n_prims;
-        if (!c->erec_valid || memcmp(c->erec_eye, a.p.eye, sizeof(c->erec_eye)) != 0) {
-            hipLaunchKernelGGL(k_eye_records, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0], a.p.eye[1],
-                               a.p.eye[2], c->d_erec);
+        const bool wide = uses_tile_kernel(c->opt_kernel, a.mode, depth, c->built_leaf_max);
+        if (wide && c->cap_erec_wide < m) {
+            (void)hipFree(c->d_erec_wide);
+            c->d_erec_wide = nullptr;
+            c->cap_erec_wide = 0;
+            CHK(c, hipMalloc(&c->d_erec_wide, (size_t)m * 4 * sizeof(float4) + 256));
+            c->cap_erec_wide = m;
+            c->erec_valid = false;
+        }
+        if (!c->erec_valid || c->erec_is_wide != wide || memcmp(c->erec_eye, a.p.eye, sizeof(c->erec_eye)) != 0) {
+            if (wide)
+                hipLaunchKernelGGL(k_eye_records_wide, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0],
+                                   a.p.eye[1], a.p.eye[2], c->d_erec_wide);
+            else
+                hipLaunchKernelGGL(k_eye_records, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0], a.p.eye[1],
+                                   a.p.eye[2], c->d_erec);
             memcpy(c->erec_eye, a.p.eye, sizeof(c->erec_eye));
             c->erec_valid = true;
+            c->erec_is_wide = wide;
         }
-        a.erec = c->d_erec;
+        a.erec = wide ? c->d_erec_wide : c->d_erec;
     }
     LaunchAux aux;
     aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
@@ -569,6 +610,23 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.tile_band = (float)c->opt_tile_band / 1024.0f;
     a.tile_look = (float)c->opt_tile_look / 1024.0f;
     a.tile_reserve = (uint32_t)c->opt_tile_reserve;
+    a.tile_prio_div = (uint32_t)c->opt_tile_prio;
+    a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
+    if (tile_kernel) {
+        // pool of window-overflow bags: a chunk (kTileOvfChunkBytes) per tile that overflows; sized for a quarter of the
+        // tiles (a tile that finds the pool empty falls back to another pass — slower, never wrong)
+        const uint32_t want = std::max(256u, a.n_blocks);
+        if (c->ovf_chunks < want) {
+            (void)hipFree(c->d_ovf);
+            c->d_ovf = nullptr;
+            c->ovf_chunks = 0;
+            CHK(c, hipMalloc(&c->d_ovf, (size_t)want * kTileOvfChunkBytes));
+            c->ovf_chunks = want;
+        }
+        if (!c->d_ovf_next) CHK(c, hipMalloc(&c->d_ovf_next, sizeof(uint32_t)));
+        CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
+        a.ovf_pool = c->d_ovf; a.ovf_next = c->d_ovf_next; a.ovf_chunks = c->ovf_chunks;
+    }
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);

@@ -55,7 +55,8 @@ struct RenderArgs {
     grt_params p;
     // Gaussian scene
     const float4* rec;    // [n_prox*4] Morton-sorted proxy records (see grt_api.hip: k_gather_records)
-    const float4* erec;   // [n_prox] per-eye part of the proxy test, same order (k_eye_records); camera frames only
+    const float4* erec;   // per-eye part of the proxy test, same order; camera frames only: [n_prox] (k_eye_records) for the
+                          // streaming kernel, [n_prox*4] (k_eye_records_wide) for the tile kernel
     const float4* nodes;
     const float4* wnodes; // 4-wide records (streaming kernel)
     const float4* qnodes; // 4-wide records, one 32-B slot per child (tile kernel)
@@ -95,6 +96,10 @@ struct RenderArgs {
     float tile_band;         // particles within F * (1 + band) of the front are tested in one batch
     float tile_look;         // nodes within Fn * (1 + look) are expanded in one step
     uint32_t tile_reserve;   // free frontier slots below which leaf steps are forced
+    uint32_t tile_prio_div;  // the first 1/div of the cost-sorted launch order runs at raised wave priority (0 = off)
+    float4* ovf_pool;        // window overflow bags: [chunk][entry][lane] x 16 B, one chunk per tile that overflows
+    uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
+    uint32_t ovf_chunks;     // chunks in the pool
     // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
     float4* prec;      // [n_blocks*256][3] primary mesh-hit records
     float4* queue;     // [n_blocks*256][4] compacted continuation rays
@@ -115,6 +120,8 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
                          std::string* err);
 int launch_render_tile(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 8;
+constexpr uint32_t kTileOvfEntries = 96; // GRT_TILE_OVF of grt_render_tile.hip
+constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
 // GRT_OPT_KERNEL values: 0 auto, 1 per-lane, 2 round-based wave, 3 streaming, 4 big-window streaming (testing), 5 tile
 constexpr int GRT_KERNEL_MAX = 5;
 // true when the launch runs on a wave-per-tile kernel (streaming or tile kernel; alone, or as stage 2 of the mesh
@@ -143,7 +150,10 @@ struct grt_ctx {
     int opt_kernel = 0;
     int opt_leaf_max = 4;
     int opt_swizzle = 2;
-    int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24; // band / look in 1/1024
+    int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24, opt_tile_prio = 0; // band / look in 1/1024
+    float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags
+    uint32_t* d_ovf_next = nullptr;
+    uint32_t ovf_chunks = 0;
     int built_leaf_max = 4; // leaf_max of the current Gaussian BVH (the tile kernel expands ranges of <= 4)
     // uploaded attributes (original order)
     uint64_t n = 0;
@@ -155,6 +165,9 @@ struct grt_ctx {
     grt::DevBvh gbvh;
     float4* d_rec = nullptr;
     float4* d_erec = nullptr;   // per-eye records of the streaming kernel (grt_api.hip: k_eye_records)
+    float4* d_erec_wide = nullptr; // 64-B eye records of the tile kernel (k_eye_records_wide)
+    size_t cap_erec_wide = 0;
+    bool erec_is_wide = false;
     float erec_eye[3] = {0, 0, 0};
     bool erec_valid = false;
     size_t cap_rec = 0;

@@ -45,7 +45,8 @@ constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kerne
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
 constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
 constexpr uint32_t kMaxIters = 1u << 21; // steps of one tile before the watchdog gives up (a heavy C3 tile takes ~2000)
-constexpr uint32_t kKeep = 40u;  // frontier entries kept in registers by a rebalance (the nearest ones)
+constexpr uint32_t kKeep = 40u;
+constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's overflow bag (entries of 16 B, in global memory)  // frontier entries kept in registers by a rebalance (the nearest ones)
 
 #ifndef GRT_TILE_WAVES
 #define GRT_TILE_WAVES 4
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
     Cnt c, w;
     (void)w;
     const uint32_t unit = a.order ? a.order[rank] : rank;
+    // the heaviest tiles of the previous frame (the head of the cost-sorted order) bound the frame: they issue first
+    if (a.order && a.tile_prio_div && rank < gridDim.x / a.tile_prio_div) __builtin_amdgcn_s_setprio(2);
     const uint32_t blk = unit >> 2, wave = unit & 3u, lane = threadIdx.x;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
     uint32_t px, py;
@@ -186,9 +189,6 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             e_ = (axx <= ayy && axx <= azz) ? mk3(1, 0, 0) : ((ayy <= azz) ? mk3(0, 1, 0) : mk3(0, 0, 1));
         }
         const f3 uu = normalize3(cross3(ax, e_)), vv = cross3(ax, uu);
-        const float da = dot3(d, ax);
-        const float ida = 1.0f / fmaxf(da, 1e-6f);
-        const float tu = dot3(d, uu) * ida, tv = dot3(d, vv) * ida;
         // The frustum bounds the lanes that still WANT something (GRT_FRUSTUM(mask)): all rays at first; re-fitted when
         // half of them have finished (saturated, or past their window cut-off), so that a few straggling rays do not
         // drag the whole tile's frustum through the rest of the scene.
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         }
 #define GRT_FRUSTUM(M)                                                                                     \
         {                                                                                                  \
+            const float da = dot3(d, ax);                                                                  \
+            const float ida = 1.0f / fmaxf(da, 1e-6f);                                                     \
+            const float tu = dot3(d, uu) * ida, tv = dot3(d, vv) * ida;                                    \
             /* a tile wider than ~75 degrees (tiny fisheye frames) gets no culling at all: every box passes */ \
             const float pk_ = (uni(wave_fmin((M) ? da : 1.0f)) >= 0.25f) ? 1.0f : 0.0f;                    \
             float tu0 = uni(wave_fmin((M) ? tu : INFINITY)), tu1 = uni(wave_fmax((M) ? tu : -INFINITY));   \
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         uint32_t pmask = 0; // payload cells in use
         uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
         bool watchdog = false;
+        uint32_t chunk = kNoRoot; // this tile's chunk of the overflow pool (taken at the first window overflow)
         const uint32_t ready_min = a.tile_ready_min; // lanes with a final event before a compositing sweep starts
 
         while (wave_any(alive)) { // one iteration = one front-to-back pass
@@ -236,7 +240,15 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             GRT_D(rounds, 1)
             const uint64_t pass_lo = last_key; // events with key <= pass_lo were composited by an earlier pass
             const float t_lo = key_t(pass_lo);
-            uint64_t cutoff = kKeyInvalid; // smallest key this lane had to drop in this pass
+            // Window overflow: the particle that no longer fits (the farthest of the 12 + 1) goes to the lane's BAG in
+            // global memory (16 B: key, exit t, alpha) instead of being dropped; `cutoff` is the smallest key that is not
+            // in the window (bag or lost) and compositing never passes it; when a lane's next event sits in its bag the
+            // bag is scanned once and the 12 smallest keys of (window + bag) are back in the window.  Only a full bag (or
+            // an exhausted pool) really loses an event (`lost`), which costs that lane another pass as before.
+            uint64_t bagmin = kKeyInvalid; // smallest key in this lane's bag
+            uint64_t lost = kKeyInvalid;   // smallest key this lane had to drop for good in this pass
+            uint32_t nb = 0;               // entries in this lane's bag
+            bool bags = false;             // some lane has a non-empty bag (wave-uniform)
             k0 = k1 = k2 = k3 = k4 = k5 = k6 = k7 = k8 = k9 = k10 = k11 = kKeyInvalid;
             pmask = 0;
             // wave-level interval of interest: nothing beyond LIM, nothing that ends before LO (stale values are
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     }
                     F = fminf(Ff, Fbag);
                     // lanes that still want something in this pass: alive and not yet past their window cut-off
-                    const float ct_ = (cutoff != kKeyInvalid) ? key_t(cutoff) : t_hi_m;
+                    const float ct_ = (lost != kKeyInvalid) ? key_t(lost) : t_hi_m;
                     const bool act = alive && (ct_ >= F);
                     const uint32_t nact = (uint32_t)__popcll(wave_ballot(act));
                     if (nact == 0u) F = INFINITY; // nothing left to find: the pass is over
@@ -357,12 +369,62 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 if (!dfs) {
                     bool sweep = done;
                     while (true) {
-                        const bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < cutoff);
+                        const bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
                         const uint64_t cm_ = wave_ballot(can_);
-                        if (!cm_) break;
+                        // a lane whose next final event sits in its bag needs a refill before it can go on
+                        const bool need = bags && alive && (nb != 0u) && !can_ && (key_t(bagmin) < F) && (bagmin < lost) &&
+                                          ((k0 == kKeyInvalid) || (k0 >= bagmin));
+                        const uint64_t nm_ = bags ? wave_ballot(need) : 0ull;
+                        if (!(cm_ | nm_)) break;
                         if (!sweep) {
-                            sweep = ((uint32_t)__popcll(cm_) >= ready_min) || wave_any(can_ && (KPRESS != kKeyInvalid));
+                            sweep = ((uint32_t)__popcll(cm_ | nm_) >= ready_min) || wave_any(can_ && (KPRESS != kKeyInvalid));
                             if (!sweep) break;
+                        }
+                        if (!cm_) {
+                            // ---- refill: one scan of the bags of the lanes in need; entry by entry, whatever is smaller
+                            //      than the window's last key goes in (sorted insert) and the displaced last key takes
+                            //      its place in the bag (compacted in place: position w <= i) ----
+                            GRT_D(node_visits, 1)
+                            uint32_t nmax = need ? nb : 0u;
+                            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+                            nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+                            uint32_t w_ = 0;
+                            uint64_t newmin = kKeyInvalid;
+                            float4* bp = a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane;
+                            for (uint32_t i = 0; i < nmax; i++) {
+                                const bool v_ = need && (i < nb);
+                                float4 e_ = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (v_) e_ = bp[(size_t)i * 64u];
+                                const uint64_t ekey = ((uint64_t)__float_as_uint(e_.y) << 32) | (uint64_t)__float_as_uint(e_.x);
+                                const bool fullw = KLAST != kKeyInvalid;
+                                const bool tk = v_ && (!fullw || (ekey < KLAST));
+                                float4 st_ = e_; // what stays in the bag at position w
+                                if (wave_any(tk)) { // wave-uniform branch
+                                    const uint32_t lcell = (uint32_t)(KLAST & kCellMask);
+                                    if (tk && fullw) { // the displaced last key, with its payload
+                                        const uint64_t dk = KLAST | kCellMask;
+                                        st_ = make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)),
+                                                          PL_OTHER(lcell), PL_ALPHA(lcell));
+                                    }
+                                    const uint32_t cell = fullw ? lcell : (uint32_t)__builtin_ctz(~pmask);
+                                    KLAST = (tk && fullw) ? kKeyInvalid : KLAST;
+                                    pmask = tk ? (pmask | (1u << cell)) : pmask;
+                                    if (tk) { PL_OTHER(cell) = e_.z; PL_ALPHA(cell) = e_.w; }
+                                    SLOT_INSERT(tk ? ((ekey & ~kCellMask) | (uint64_t)cell) : kKeyInvalid)
+                                }
+                                const bool keep = v_ && (!tk || fullw);
+                                if (keep) {
+                                    bp[(size_t)w_ * 64u] = st_;
+                                    const uint64_t sk = ((uint64_t)__float_as_uint(st_.y) << 32) | (uint64_t)__float_as_uint(st_.x);
+                                    newmin = (sk < newmin) ? sk : newmin;
+                                    w_++;
+                                }
+                            }
+                            if (need) {
+                                nb = w_;
+                                bagmin = newmin;
+                            }
+                            continue;
                         }
                         GRT_D(hit_evals, 1)
                         const uint64_t ek = k0;
@@ -477,7 +539,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 const bool valid = cv && (cref != kNoRoot);
                 if (COUNT && valid) c.node_visits++; // one 32-B child box per lane
                 if (lim_dirty) { // a window overflowed: lanes past their cutoff want nothing any more
-                    const float ct2_ = (cutoff != kKeyInvalid) ? key_t(cutoff) : t_hi_m;
+                    const float ct2_ = (lost != kKeyInvalid) ? key_t(lost) : t_hi_m;
                     LIM = uni(wave_fmax(alive ? ct2_ : 0.0f));
                     lim_dirty = false;
                 }
@@ -519,8 +581,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                         const uint32_t ridx = pidx * 4u;
                         const float4 r0 = sload4(a.rec, ridx), r1 = sload4(a.rec, ridx + 1), r2 = sload4(a.rec, ridx + 2),
                                      r3 = sload4(a.rec, ridx + 3);
-                        const float4 e0 = sload4(a.erec, pidx);
-                        if (COUNT) c.fetches += 5; // wave-uniform: 64-B record + 16-B eye record, in 16-B units
+                        const float4 e0 = sload4(a.erec, ridx), e1 = sload4(a.erec, ridx + 1), e2 = sload4(a.erec, ridx + 2),
+                                     e3 = sload4(a.erec, ridx + 3);
+                        if (COUNT) c.fetches += 8; // wave-uniform: 64-B record + 64-B eye record, in 16-B units
                         const f3 mu = mk3(r0.x, r0.y, r0.z);
                         m33 A;
                         A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
@@ -537,14 +600,15 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                         if (COUNT && alive) c.proxy_tests++;
                         GRT_D(proxy_tests, 1)
                         float te, tx;
-                        const bool hit = proxy_slabs(o_g, d_g, r0.w, te, tx) && alive;
+                        const float pa[10] = {e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y}; // slab_project(o_g)
+                        const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && alive;
                         const uint32_t id = __float_as_uint(r2.w);
                         const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
                         // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
                         const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > pass_lo);
                         const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
                         const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
-                        const bool ins = (k_first != kKeyInvalid) && (k_first < cutoff);
+                        const bool ins = (k_first != kKeyInvalid) && (k_first < lost);
                         if (wave_any(ins)) { // wave-uniform branch
                             // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
                             const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
@@ -553,10 +617,29 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                             // the lane becomes lossy beyond it
                             const bool full = KLAST != kKeyInvalid;
                             const bool take = ins && (!full || k_first < KLAST);
-                            const uint64_t dropped = (ins && full) ? (take ? (KLAST | kCellMask) : k_first) : kKeyInvalid;
-                            if (wave_any(dropped != kKeyInvalid)) lim_dirty = true;
-                            cutoff = (dropped < cutoff) ? dropped : cutoff;
+                            const bool drop = ins && full; // the farthest of (window + new particle) leaves the window
                             const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
+                            if (wave_any(drop)) { // wave-uniform branch: into the lane's bag
+                                if (chunk == kNoRoot) { // first overflow of this tile: take a chunk of the pool
+                                    uint32_t ch = 0;
+                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u);
+                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); // pool exhausted: drop for good
+                                }
+                                const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
+                                const bool to_bag = drop && (chunk < a.ovf_chunks) && (nb < kOvf);
+                                if (to_bag) {
+                                    const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
+                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
+                                        make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a);
+                                    nb++;
+                                    bagmin = (dk < bagmin) ? dk : bagmin;
+                                }
+                                const bool gone = drop && !to_bag;
+                                lost = (gone && (dk < lost)) ? dk : lost;
+                                bags = true;
+                                if (wave_any(gone)) lim_dirty = true;
+                            }
                             KLAST = (take && full) ? kKeyInvalid : KLAST;
                             pmask = take ? (pmask | (1u << cell)) : pmask;
                             if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; }
@@ -599,7 +682,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             // a lane goes again only if it dropped something and still has transmittance left
             const bool progressed = last_key != pass_lo;
             stalls = progressed ? 0u : stalls + 1u;
-            const bool again = alive && (cutoff != kKeyInvalid);
+            const bool again = alive && (lost != kKeyInvalid);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
             alive = again && (stalls < 2u) && !watchdog;
         }

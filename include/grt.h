@@ -134,7 +134,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event before a compositing sweep starts, 1..64 (16) */,
        GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (16) */,
        GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (32) */,
-       GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */ };
+       GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */,
+       GRT_OPT_TILE_PRIO_DIV = 12     /* the heaviest 1/value of the tiles (by last frame's cost) run at raised wave priority; 0 = off */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
