@@ -334,19 +334,61 @@ __global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restr
     w[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Per-child layout of the same 4-wide tree for the tile kernel (one lane tests one child box: 2 x 16-B loads).
-__global__ void k_qwiden(const float4* __restrict__ wn, int m, float4* __restrict__ qn)
+// Per-child layout for the tile kernel (one lane tests one child box: 2 x 16-B loads), kTileWide children per node:
+// record i = the descendants of binary node i up to log2(kTileWide) levels down (a leaf range stays as it is, and an
+// internal descendant stops being expanded once the record is full).  Child c at [i*2W + 2c] = (lo.xyz, ref bits),
+// [i*2W + 2c + 1] = (hi.xyz, 0); unused child: ref kNoRoot with an inverted box.
+__global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __restrict__ qn)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m - 1) return;
-    const float4* w = wn + (size_t)i * 8;
-    const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
-    // wide record: per child (lo.x lo.y | hi.x hi.y | lo.z hi.z)
-    float4* q = qn + (size_t)i * 8;
-    q[0] = make_float4(w0.x, w0.y, w1.x, w6.x); q[1] = make_float4(w0.z, w0.w, w1.y, 0.0f);
-    q[2] = make_float4(w1.z, w1.w, w2.z, w6.y); q[3] = make_float4(w2.x, w2.y, w2.w, 0.0f);
-    q[4] = make_float4(w3.x, w3.y, w4.x, w6.z); q[5] = make_float4(w3.z, w3.w, w4.y, 0.0f);
-    q[6] = make_float4(w4.z, w4.w, w5.z, w6.w); q[7] = make_float4(w5.x, w5.y, w5.w, 0.0f);
+    constexpr int W = (int)kTileWide;
+    float box[W][6];
+    uint32_t ref[W];
+    int ne = 0;
+    auto push_children = [&](uint32_t node, float (*b)[6], uint32_t* r, int& n) {
+        const size_t q = (size_t)node * 4;
+        const float4 q0 = nodes[q], q1 = nodes[q + 1], q2 = nodes[q + 2], q3 = nodes[q + 3];
+        b[n][0] = q0.x; b[n][1] = q0.y; b[n][2] = q0.z; b[n][3] = q0.w; b[n][4] = q1.x; b[n][5] = q1.y;
+        r[n++] = __float_as_uint(q3.x);
+        b[n][0] = q1.z; b[n][1] = q1.w; b[n][2] = q2.x; b[n][3] = q2.y; b[n][4] = q2.z; b[n][5] = q2.w;
+        r[n++] = __float_as_uint(q3.y);
+    };
+    push_children((uint32_t)i, box, ref, ne);
+    for (int round = 1; (2 << round) <= W; round++) { // each round expands every internal entry that still fits
+        float nb[W][6];
+        uint32_t nr[W];
+        int nn = 0;
+        const int internal_left_init = [&] { int k = 0; for (int e = 0; e < ne; e++) k += (ref[e] & kLeafBit) ? 0 : 1; return k; }();
+        int internal_left = internal_left_init;
+        for (int e = 0; e < ne; e++) {
+            const bool internal = !(ref[e] & kLeafBit);
+            // expanding turns 1 entry into 2: allowed while the final count (entries so far + the rest + 1) fits
+            const int rest = ne - e - 1;
+            if (internal && (nn + 2 + rest) <= W) {
+                push_children(ref[e], nb, nr, nn);
+            } else {
+                for (int k = 0; k < 6; k++) nb[nn][k] = box[e][k];
+                nr[nn++] = ref[e];
+            }
+            (void)internal_left;
+        }
+        for (int e = 0; e < nn; e++) {
+            for (int k = 0; k < 6; k++) box[e][k] = nb[e][k];
+            ref[e] = nr[e];
+        }
+        ne = nn;
+    }
+    float4* q = qn + (size_t)i * 2 * W;
+    for (int e = 0; e < W; e++) {
+        if (e < ne) {
+            q[2 * e] = make_float4(box[e][0], box[e][1], box[e][2], __uint_as_float(ref[e]));
+            q[2 * e + 1] = make_float4(box[e][3], box[e][4], box[e][5], 0.0f);
+        } else {
+            q[2 * e] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(kNoRoot));
+            q[2 * e + 1] = make_float4(-1.0f, -1.0f, -1.0f, 0.0f);
+        }
+    }
 }
 
 __global__ void k_pbox(const float4* __restrict__ lb_lo, const float4* __restrict__ lb_hi, uint32_t m,
@@ -488,8 +530,8 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
     hipLaunchKernelGGL(k_widen, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->wnodes);
     if (want_quad) {
-        HIPCHK(hipMalloc(&out->qnodes, sizeof(float4) * 8 * (size_t)(m - 1) + 256));
-        hipLaunchKernelGGL(k_qwiden, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->wnodes, (int)m, out->qnodes);
+        HIPCHK(hipMalloc(&out->qnodes, sizeof(float4) * 2 * kTileWide * (size_t)(m - 1) + 256));
+        hipLaunchKernelGGL(k_qwiden, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->qnodes);
     }
     HIPCHK(hipStreamSynchronize(stream));
 done:

@@ -20,6 +20,11 @@ constexpr uint32_t kLeafMaxPrims = 8u;
 __host__ __device__ inline uint32_t leaf_first(uint32_t ref) { return ref & kLeafIndexMask; }
 __host__ __device__ inline uint32_t leaf_count(uint32_t ref) { return ((ref >> 28) & 7u) + 1u; }
 constexpr uint32_t kNoRoot = 0xFFFFFFFFu;
+// children per node in the tile kernel's view of the tree (DevBvh::qnodes): 4, 8 or 16
+#ifndef GRT_TILE_WIDE
+#define GRT_TILE_WIDE 8
+#endif
+constexpr uint32_t kTileWide = GRT_TILE_WIDE;
 
 // LBVH in traversal layout.  One 64-B record (4 x float4) per INTERNAL node holding the boxes of
 // its two children, so a node fetch decides both descents:
@@ -30,9 +35,9 @@ struct DevBvh {
     float4* wnodes = nullptr;  // [(n_prims-1) * 8] 4-wide view of the same tree (two binary levels per record):
                                //   24 floats = 4 child boxes, each (lo.x lo.y | hi.x hi.y | lo.z hi.z),
                                //   W6 = 4 child refs, W7 pad; an unused child has ref kNoRoot
-    float4* qnodes = nullptr;  // [(n_prims-1) * 8] the same 4-wide tree laid out per CHILD for the tile kernel
-                               //   (grt_render_tile.hip: one lane tests one child box): child c of node i at
-                               //   [i*8 + 2c] = (lo.xyz, ref bits), [i*8 + 2c + 1] = (hi.xyz, 0); unused child: ref kNoRoot
+    float4* qnodes = nullptr;  // [(n_prims-1) * 2 * kTileWide] the tree laid out per CHILD for the tile kernel
+                               //   (grt_render_tile.hip: one lane tests one child box), kTileWide children per record:
+                               //   child c of node i at [i*2W + 2c] = (lo.xyz, ref bits), [+1] = (hi.xyz, 0); unused: ref kNoRoot
     float4* pbox = nullptr;    // [n_prims * 2] box of every sorted primitive, (lo.xyz,0)(hi.xyz,0): what a leaf-range
                                //   child expands to in the tile kernel (built only for the Gaussian BVH)
     uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
@@ -122,7 +127,8 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, hipStream_t s
 constexpr int kNumCounters = 8;
 constexpr uint32_t kTileOvfEntries = 96; // GRT_TILE_OVF of grt_render_tile.hip
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
-// GRT_OPT_KERNEL values: 0 auto, 1 per-lane, 2 round-based wave, 3 streaming, 4 big-window streaming (testing), 5 tile
+// GRT_OPT_KERNEL values: 0 auto (tile kernel where it applies, else streaming), 1 per-lane, 2 round-based wave,
+// 3 streaming, 4 big-window streaming (testing), 5 tile
 constexpr int GRT_KERNEL_MAX = 5;
 // true when the launch runs on a wave-per-tile kernel (streaming or tile kernel; alone, or as stage 2 of the mesh
 // wavefront pipeline): its scheduling units are 8x8 tiles (4 per 16x16 block).  ONE predicate for do_launch (sizes
@@ -134,7 +140,7 @@ inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
 // the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
 inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max)
 {
-    return uses_stream_kernel(variant, mode, stack_depth) && variant == 5 && built_leaf_max <= 4;
+    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4;
 }
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,

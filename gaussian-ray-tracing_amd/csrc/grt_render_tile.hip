@@ -45,6 +45,7 @@ constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kerne
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
 constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
 constexpr uint32_t kMaxIters = 1u << 21; // steps of one tile before the watchdog gives up (a heavy C3 tile takes ~2000)
+constexpr uint32_t kStack = 384u; // depth-first overflow stack (only when the LDS bag is full too)
 constexpr uint32_t kKeep = 40u;
 constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's overflow bag (entries of 16 B, in global memory)  // frontier entries kept in registers by a rebalance (the nearest ones)
 
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
-    __shared__ uint32_t dstack[288]; // depth-first overflow: the batch that overflowed (<= 64) + 3 siblings per level
+    __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + 3 siblings per level
                                  // below it (<= 3 * 62 for the tree heights the launcher sends here)
     Cnt c, w;
     (void)w;
@@ -477,12 +478,14 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 //      nodes -> their children's boxes are culled and the survivors join the frontier ----
                 const bool occ_l = fr != kNoRoot;
                 const bool rng_l = occ_l && ((fr & kLeafBit) != 0u);
-                const uint32_t g = lane >> 2, j = lane & 3u;
                 bool leaf_step;
                 uint32_t nref; // the entry this lane's group expands
                 bool gv;       // group valid
+                uint32_t g, j; // group of this lane and its child slot in the group: 4 lanes per leaf range, kTileWide per node
                 if (cur != kNoRoot) { // depth-first mode: one entry
                     leaf_step = (cur & kLeafBit) != 0u;
+                    g = leaf_step ? (lane >> 2) : (lane / kTileWide);
+                    j = leaf_step ? (lane & 3u) : (lane % kTileWide);
                     nref = cur;
                     gv = g == 0u;
                 } else {
@@ -500,7 +503,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     const bool cand = occ_l && (rng_l == leaf_step);
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
                     // one node: a frontier full of internal nodes overflows to the depth-first stack)
-                    const uint32_t maxb = leaf_step ? kBatch : max(min(kBatch, (64u - nocc) / 3u), 1u);
+                    const uint32_t maxb = leaf_step ? kBatch : max(min(64u / kTileWide, (64u - nocc) / (kTileWide - 1u)), 1u);
+                    g = leaf_step ? (lane >> 2) : (lane / kTileWide);
+                    j = leaf_step ? (lane & 3u) : (lane % kTileWide);
                     float th = tau;
                     uint64_t sm = wave_ballot(cand && (fl <= th));
                     if ((uint32_t)__popcll(sm) > maxb) {
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 const bool cv = gv && (!leaf_step || (j < leaf_count(nref)));
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (cv) {
-                    const float4* src = leaf_step ? (a.pbox + (size_t)(first + j) * 2) : (a.qnodes + (size_t)nref * 8 + j * 2u);
+                    const float4* src = leaf_step ? (a.pbox + (size_t)(first + j) * 2) : (a.qnodes + (size_t)nref * (2u * kTileWide) + j * 2u);
                     b0 = src[0];
                     b1 = src[1];
                 }
@@ -664,6 +669,11 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                         rebal = true;
                         wave_fence();
                     } else {
+                        if (nc > nf && dsp + (nc - nf) > kStack) { // cannot happen for the tree heights the launcher admits
+                            c.stall_exits += alive ? 1u : 0u;
+                            watchdog = true;
+                            break;
+                        }
                         if (want) {
                             if (crk < nf) xch[crk] = make_uint2(__float_as_uint(lam), cref);
                             else dstack[dsp + (crk - nf)] = cref; // bag full too: depth-first from here on

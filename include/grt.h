@@ -114,12 +114,12 @@ typedef struct {
 } grt_bvh_info;
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
-       GRT_OPT_KERNEL = 2   /* 0 = auto (single-pass streaming wave kernel for camera rays, wavefront pipeline for
-                               mesh frames, per-lane kernel for ray buffers),
+       GRT_OPT_KERNEL = 2   /* 0 = auto: camera-ray frames on the tile kernel (grt_render_tile.hip: BVH culling per child box
+                               against the tile frustum; also stage 2 of the wavefront pipeline of mesh frames) — or on the
+                               streaming kernel when the BVH was built with GRT_OPT_LEAF_MAX > 4; ray buffers on the per-lane kernel.
                                1 = per-lane kernel everywhere, 2 = round-based wave kernel for camera rays without meshes
-                               (per-lane otherwise),
-                               3 = streaming kernel, 4 = its 32-slot variant everywhere (testing),
-                               5 = tile kernel (grt_render_tile.hip: BVH culling per child box against the tile frustum) */,
+                               (per-lane otherwise), 3 = streaming kernel, 4 = its 32-slot variant everywhere (testing),
+                               5 = same as 0 */,
        GRT_OPT_LEAF_MAX = 3 /* max primitives per BVH leaf, 1..8 (default 4); applies to the next build */,
        GRT_OPT_SWIZZLE = 4  /* XCD-aware launch order: runs of value 16x16 screen blocks (4 x value 8x8 tiles of the
                                streaming kernel) go to one XCD, i.e. one L2 (0 = identity; default 2) */,

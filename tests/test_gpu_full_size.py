@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's full sizes (C3: 1 M Gaussians at 1920x1080; C5: 3 M at 3840x2160 fisheye) through
 properties that do not need the oracle to render the whole frame:
-  * kernel independence: the streaming kernel, the round-based wave kernel and (on a window) the per-lane kernel are
-    three separate implementations of the traversal and must agree bit for bit;
+  * kernel independence: the tile kernel (default), the streaming kernel, the round-based wave kernel and (on a window)
+    the per-lane kernel are four separate implementations of the traversal and must agree bit for bit;
   * shard independence: the 8-rank tile split, un-permuted, is the full frame;
   * schedule independence: frames launched in cost order (scheduling feedback, big-window split) are unchanged;
   * the oracle itself on sampled windows, including the frame's heaviest tiles (radiance within 1e-4, 8-bit within 1).
@@ -27,9 +27,10 @@ def test_c3_full_size_properties_and_oracle_windows():
     u8, f32 = u8.clone(), f32.clone()
     assert int(u8.sum().item()) > 0
     # ---- kernel independence ----
-    tr.set_option(grt.OPT_KERNEL, 2)
-    a8, af = tr.render(p, want_f32=True)
-    assert (a8 == u8).all() and (af == f32).all()
+    for kernel in (2, 3):
+        tr.set_option(grt.OPT_KERNEL, kernel)
+        a8, af = tr.render(p, want_f32=True)
+        assert (a8 == u8).all() and (af == f32).all(), kernel
     tr.set_option(grt.OPT_KERNEL, 1)
     win = (640, 536, 832, 664)  # around the heaviest tiles of this frame
     w8 = torch.zeros_like(u8); wf = torch.zeros_like(f32)
@@ -38,11 +39,13 @@ def test_c3_full_size_properties_and_oracle_windows():
     assert (w8[y0:y1, x0:x1] == u8[y0:y1, x0:x1]).all() and (wf[y0:y1, x0:x1] == f32[y0:y1, x0:x1]).all()
     tr.set_option(grt.OPT_KERNEL, 0)
     # ---- schedule independence: steady-state frames (heaviest-first), forced big-window split ----
-    for fb in (1, 5):
+    for kernel, fb in ((0, 1), (3, 1), (3, 5)):
+        tr.set_option(grt.OPT_KERNEL, kernel)
         tr.set_option(grt.OPT_FEEDBACK, fb)
         for _ in range(3):
             a8, af = tr.render(p, want_f32=True)
-        assert (a8 == u8).all() and (af == f32).all(), fb
+        assert (a8 == u8).all() and (af == f32).all(), (kernel, fb)
+    tr.set_option(grt.OPT_KERNEL, 0)
     tr.set_option(grt.OPT_FEEDBACK, 1)
     # ---- shard independence: 8 ranks ----
     world = 8
@@ -77,9 +80,10 @@ def test_c5_full_size_fisheye_kernel_and_shard_independence():
     u8, _ = tr.render(p)
     u8 = u8.clone()
     assert (u8[:8, :8] == 0).all()  # fisheye: r > 1 is black
-    tr.set_option(grt.OPT_KERNEL, 2)
-    a8, _ = tr.render(p)
-    assert (a8 == u8).all()
+    for kernel in (2, 3):
+        tr.set_option(grt.OPT_KERNEL, kernel)
+        a8, _ = tr.render(p)
+        assert (a8 == u8).all(), kernel
     tr.set_option(grt.OPT_KERNEL, 0)
     world = 8
     tx, ty = tiles.grid(W, H, 32)

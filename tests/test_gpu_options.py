@@ -17,7 +17,7 @@ def test_options_do_not_change_pixels():
     for leaf_max in (1, 2, 8):
         tr.set_option(grt.OPT_LEAF_MAX, leaf_max)
         tr.upload(acts)
-        for kernel in (0, 1, 2):
+        for kernel in (0, 1, 2, 3):
             tr.set_option(grt.OPT_KERNEL, kernel)
             a8, af = tr.render(p, want_f32=True)
             assert (a8 == ref8).all() and (af == reff).all(), (leaf_max, kernel)
@@ -26,11 +26,24 @@ def test_options_do_not_change_pixels():
         tr.set_option(grt.OPT_SWIZZLE, swz)
         a8, af = tr.render(p, want_f32=True)
         assert (a8 == ref8).all() and (af == reff).all(), swz
-    for fb in (0, 1, 3, 5):  # 5 = heaviest-first + big-window kernel for the heaviest blocks on a second stream
-        tr.set_option(grt.OPT_FEEDBACK, fb)
-        for _ in range(3):
-            a8, af = tr.render(p, want_f32=True)
-            assert (a8 == ref8).all() and (af == reff).all(), fb
+    for kernel in (0, 3):
+        tr.set_option(grt.OPT_KERNEL, kernel)
+        for fb in (0, 1, 3, 5):  # 5 = heaviest-first + (streaming kernel) big-window kernel for the heaviest tiles
+            tr.set_option(grt.OPT_FEEDBACK, fb)
+            for _ in range(3):
+                a8, af = tr.render(p, want_f32=True)
+                assert (a8 == ref8).all() and (af == reff).all(), (kernel, fb)
+    tr.set_option(grt.OPT_KERNEL, 0); tr.set_option(grt.OPT_FEEDBACK, 1)
+    # tile kernel tuning: batch sizes, compositing deferral, frontier reserve, priority
+    for opt, vals in ((grt.OPT_TILE_READY_MIN, (1, 64)), (grt.OPT_TILE_BAND, (0, 1024)), (grt.OPT_TILE_LOOKAHEAD, (0, 1024)),
+                      (grt.OPT_TILE_RESERVE, (0, 60)), (grt.OPT_TILE_PRIO_DIV, (4,))):
+        for v in vals:
+            tr.set_option(opt, v)
+            for _ in range(2):
+                a8, af = tr.render(p, want_f32=True)
+                assert (a8 == ref8).all() and (af == reff).all(), (opt, v)
+        tr.set_option(opt, {grt.OPT_TILE_READY_MIN: 16, grt.OPT_TILE_BAND: 64, grt.OPT_TILE_LOOKAHEAD: 64,
+                            grt.OPT_TILE_RESERVE: 24, grt.OPT_TILE_PRIO_DIV: 0}[opt])
     with pytest.raises(grt.GrtError):
         tr.set_option(grt.OPT_LEAF_MAX, 9)
     with pytest.raises(grt.GrtError):
@@ -49,15 +62,17 @@ def test_split_launch_with_mesh_and_tiles():
     tr.set_option(grt.OPT_FEEDBACK, 0)
     ref8, _ = tr.render(p)
     ref8 = ref8.clone()
-    tr.set_option(grt.OPT_FEEDBACK, 5)
-    for _ in range(3):
-        a8, _ = tr.render(p)
-        assert (a8 == ref8).all()
-    tiles8 = torch.zeros((6 * 4, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
-    for _ in range(3):
-        tr.render_tiles(p, 32, 32, 0, 1, 24, out_u8=tiles8)
-    img = tiles8.reshape(4, 6, 32, 32, 3).permute(0, 2, 1, 3, 4).reshape(128, 192, 3)
-    assert (img == ref8).all()
+    for kernel in (0, 3):
+        tr.set_option(grt.OPT_KERNEL, kernel)
+        tr.set_option(grt.OPT_FEEDBACK, 5)
+        for _ in range(3):
+            a8, _ = tr.render(p)
+            assert (a8 == ref8).all(), kernel
+        tiles8 = torch.zeros((6 * 4, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+        for _ in range(3):
+            tr.render_tiles(p, 32, 32, 0, 1, 24, out_u8=tiles8)
+        img = tiles8.reshape(4, 6, 32, 32, 3).permute(0, 2, 1, 3, 4).reshape(128, 192, 3)
+        assert (img == ref8).all(), kernel
     tr.close()
 
 

@@ -15,12 +15,12 @@ TOL = 1e-4
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_probes.json")))
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2, 5], ids=["stream", "perlane", "wave", "tile"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["tile", "perlane", "wave", "stream"])
 def tr(request):
-    """Every parity test runs on each traversal path (GRT_OPT_KERNEL): 0 = default (single-pass streaming wave
-    kernel; wavefront pipeline when meshes are present), 1 = per-lane megakernel everywhere, 2 = round-based
-    wave kernel (per-lane megakernel when meshes are present), 5 = tile kernel (BVH culling per child box against the
-    tile frustum; also stage 2 of the wavefront pipeline when meshes are present)."""
+    """Every parity test runs on each traversal path (GRT_OPT_KERNEL): 0 = default (tile kernel: BVH culling per
+    child box against the tile frustum; stage 2 of the wavefront pipeline when meshes are present), 1 = per-lane
+    megakernel everywhere, 2 = round-based wave kernel (per-lane megakernel when meshes are present), 3 = single-pass
+    streaming wave kernel (round 1's default)."""
     t = grt.Tracer(0)
     t.set_option(grt.OPT_KERNEL, request.param)
     t.kernel_variant = request.param
@@ -73,7 +73,7 @@ def test_c1_10k_256x256_pinhole(tr):
     compare(f32, ref_f32, u8, ref_u8)
     assert cnt["rays"] == rc["rays"] == 256 * 256
     assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
-    if tr.kernel_variant not in (0, 5):  # the streaming / tile kernels replace the k = 7 rounds by (mostly) one pass
+    if tr.kernel_variant not in (0, 3):  # the streaming / tile kernels replace the k = 7 rounds by (mostly) one pass
         assert cnt["rounds"] == rc["rounds"] or abs(cnt["rounds"] - rc["rounds"]) <= 1e-4 * rc["rounds"]
     else:
         assert rc["rays"] <= cnt["rounds"] < rc["rounds"]
@@ -325,7 +325,7 @@ def test_coincident_gaussians_deep_overlap(tr):
     sc.close()
 
 
-@pytest.mark.parametrize("kernel", [0, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 3, 4])
 @pytest.mark.parametrize("n", [1, 2, 4])
 def test_tiny_scene_in_a_fresh_context(kernel, n):
     """<= leaf_max hittable proxies: the LBVH root is a leaf range and there is NO node array.  A fresh context (no
