@@ -324,4 +324,159 @@ int grt_host_ply_write(const char* path, uint64_t n, const float* pos, const flo
     return GRT_OK;
 }
 
+// ---- procedural primitives and OBJ meshes (reference src/geometry/Primitives.cpp:6-216) ----
+// Both procedural primitives are vertex LATTICES (rows x cols points) whose cells are cut into two triangles the same
+// way, so one table describes them: lattice size, whether a column is repeated to close a seam, and a per-point
+// evaluator.  The numbers a point evaluates to are the reference's (same float operations, glibc sinf/cosf):
+//   plane   0.3 x 0.5 quad in z = 0, normal +z, 2 x 2 points                      Primitives.cpp:6-61
+//   sphere  radius 0.3, 90 rings (south pole first) x 181 points (seam doubled)   Primitives.cpp:63-140
+namespace {
+struct LatticeSpec { uint32_t rows, cols; }; // points per column / per row
+const LatticeSpec kLattice[2] = {{2u, 2u}, {90u, 181u}};
+
+inline void lattice_point(int kind, uint32_t r, uint32_t c, float pos[3], float nrm[3])
+{
+    if (kind == GRT_PRIM_PLANE) {
+        const float width = 0.3f, height = 0.5f;
+        const float u = float(c) * (width / 1.0f), v = float(r) * (height / 1.0f);
+        pos[0] = -width * 0.5f + u; pos[1] = -height * 0.5f + v; pos[2] = 0.0f + 0.0f;
+        nrm[0] = 0.0f; nrm[1] = 0.0f; nrm[2] = 1.0f;
+    } else {
+        const float radius = 0.3f, pi = 3.14159265358979323846f;
+        const float phi_step = 2.0f * pi / 180.0f, theta_step = pi / 89.0f;
+        const float theta = (float)r * theta_step, phi = (float)c * phi_step;
+        const float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+        nrm[0] = cp * st; nrm[1] = ct; nrm[2] = sp * st;
+        for (int k = 0; k < 3; k++) pos[k] = nrm[k] * radius;
+    }
+}
+} // namespace
+
+int grt_host_primitive_counts(int kind, uint32_t* nv, uint32_t* nf)
+{
+    if ((kind != GRT_PRIM_PLANE && kind != GRT_PRIM_SPHERE) || !nv || !nf) { g_host_err = "grt_host_primitive_counts: bad argument"; return GRT_ERR_INVALID; }
+    const LatticeSpec& L = kLattice[kind];
+    *nv = L.rows * L.cols;
+    *nf = 2u * (L.rows - 1u) * (L.cols - 1u);
+    return GRT_OK;
+}
+
+int grt_host_primitive_fill(int kind, float* verts, float* normals, uint32_t* faces)
+{
+    if ((kind != GRT_PRIM_PLANE && kind != GRT_PRIM_SPHERE) || !verts || !normals || !faces) { g_host_err = "grt_host_primitive_fill: bad argument"; return GRT_ERR_INVALID; }
+    const LatticeSpec& L = kLattice[kind];
+    for (uint32_t r = 0; r < L.rows; r++)
+        for (uint32_t c = 0; c < L.cols; c++) lattice_point(kind, r, c, verts + 3 * (size_t)(r * L.cols + c), normals + 3 * (size_t)(r * L.cols + c));
+    // cell (r, c) -> (ll, lr, ur) (ur, ul, ll): the winding the reference emits
+    uint32_t* f = faces;
+    for (uint32_t r = 0; r + 1 < L.rows; r++)
+        for (uint32_t c = 0; c + 1 < L.cols; c++) {
+            const uint32_t ll = r * L.cols + c, lr = ll + 1u, ul = ll + L.cols, ur = ul + 1u;
+            const uint32_t six[6] = {ll, lr, ur, ur, ul, ll};
+            memcpy(f, six, sizeof(six));
+            f += 6;
+        }
+    return GRT_OK;
+}
+
+// OBJ reader (tinyobjloader is not vendored).  One (position, normal) pair is emitted per face corner, in file order,
+// exactly as the reference un-indexes tinyobj's output (Primitives.cpp:157-191); positions and normals get the Y flip
+// (:175,:179).  Polygons are fan-triangulated (tinyobj's default).  A face corner without a normal index — which the
+// reference dereferences at index -1 — is an error here; so is any parse failure (the reference calls exit(1)).
+namespace {
+struct ObjSoup { std::vector<float> v, n; };
+int obj_parse(const char* path, ObjSoup& out)
+{
+    std::ifstream f(path);
+    if (!f) { g_host_err = std::string("OBJ: cannot open ") + path; return GRT_ERR_IO; }
+    std::vector<float> vs, ns;
+    std::string line;
+    size_t lineno = 0;
+    auto fail = [&](const std::string& what) { g_host_err = "OBJ: " + what + " at line " + std::to_string(lineno) + " of " + path; return GRT_ERR_IO; };
+    auto resolve = [](long idx, size_t n, size_t* o) {
+        if (idx > 0 && (size_t)idx <= n) { *o = (size_t)idx - 1; return true; }
+        if (idx < 0 && (size_t)(-idx) <= n) { *o = n - (size_t)(-idx); return true; }
+        return false;
+    };
+    while (std::getline(f, line)) {
+        lineno++;
+        std::istringstream ss(line);
+        std::string tok;
+        if (!(ss >> tok)) continue;
+        if (tok == "v" || tok == "vn") {
+            float x, y, z;
+            if (!(ss >> x >> y >> z)) return fail(tok == "v" ? "bad vertex" : "bad normal");
+            std::vector<float>& dst = tok == "v" ? vs : ns;
+            dst.push_back(x); dst.push_back(y); dst.push_back(z);
+        } else if (tok == "f") {
+            std::vector<std::pair<size_t, size_t>> corners;
+            std::string c;
+            while (ss >> c) {
+                const size_t s1 = c.find('/');
+                const size_t s2 = s1 == std::string::npos ? std::string::npos : c.find('/', s1 + 1);
+                if (s2 == std::string::npos || s2 + 1 >= c.size()) return fail("face corner without a normal");
+                long vi = 0, ni = 0;
+                try { vi = std::stol(c.substr(0, s1)); ni = std::stol(c.substr(s2 + 1)); } catch (...) { return fail("bad face corner"); }
+                size_t a, b;
+                if (!resolve(vi, vs.size() / 3, &a)) return fail("bad vertex index");
+                if (!resolve(ni, ns.size() / 3, &b)) return fail("bad normal index");
+                corners.push_back({a, b});
+            }
+            if (corners.size() < 3) return fail("face with fewer than 3 corners");
+            for (size_t k = 1; k + 1 < corners.size(); k++)
+                for (size_t t : {(size_t)0, k, k + 1}) {
+                    const float* pv = &vs[corners[t].first * 3];
+                    const float* pn = &ns[corners[t].second * 3];
+                    out.v.push_back(pv[0]); out.v.push_back(-pv[1]); out.v.push_back(pv[2]);
+                    out.n.push_back(pn[0]); out.n.push_back(-pn[1]); out.n.push_back(pn[2]);
+                }
+        }
+    }
+    if (out.v.empty()) { g_host_err = std::string("OBJ: no faces in ") + path; return GRT_ERR_IO; }
+    return GRT_OK;
+}
+} // namespace
+
+int grt_host_obj_count(const char* path, uint32_t* nv, uint32_t* nf)
+{
+    if (!path || !nv || !nf) return GRT_ERR_INVALID;
+    ObjSoup s;
+    const int rc = obj_parse(path, s);
+    if (rc != GRT_OK) return rc;
+    *nv = (uint32_t)(s.v.size() / 3);
+    *nf = *nv / 3;
+    return GRT_OK;
+}
+
+int grt_host_obj_read(const char* path, uint32_t nv, float* verts, float* normals, uint32_t* faces)
+{
+    if (!path || !verts || !normals || !faces) return GRT_ERR_INVALID;
+    ObjSoup s;
+    const int rc = obj_parse(path, s);
+    if (rc != GRT_OK) return rc;
+    if (s.v.size() / 3 != nv) { g_host_err = "grt_host_obj_read: vertex count mismatch"; return GRT_ERR_INVALID; }
+    memcpy(verts, s.v.data(), s.v.size() * sizeof(float));
+    memcpy(normals, s.n.data(), s.n.size() * sizeof(float));
+    for (uint32_t i = 0; i < nv; i++) faces[i] = i; // un-indexed soup: face k = corners 3k, 3k+1, 3k+2
+    return GRT_OK;
+}
+
+// Writes (verts, normals, faces) as OBJ with "%.9g" (round-trips fp32 exactly), v//vn corners sharing one index.
+// The Y flip of the reader is NOT undone: write_obj(flip_y(mesh)) followed by a read gives mesh back.
+int grt_host_obj_write(const char* path, uint32_t nv, const float* verts, const float* normals, uint32_t nf, const uint32_t* faces)
+{
+    if (!path || !verts || !normals || !faces) return GRT_ERR_INVALID;
+    FILE* fp = fopen(path, "w");
+    if (!fp) { g_host_err = std::string("cannot create ") + path; return GRT_ERR_IO; }
+    for (uint32_t i = 0; i < nv; i++) fprintf(fp, "v %.9g %.9g %.9g\n", verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
+    for (uint32_t i = 0; i < nv; i++) fprintf(fp, "vn %.9g %.9g %.9g\n", normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+    for (uint32_t k = 0; k < nf; k++) {
+        const uint32_t a = faces[3 * k] + 1, b = faces[3 * k + 1] + 1, c = faces[3 * k + 2] + 1;
+        if (a > nv || b > nv || c > nv) { fclose(fp); g_host_err = "grt_host_obj_write: face index out of range"; return GRT_ERR_INVALID; }
+        fprintf(fp, "f %u//%u %u//%u %u//%u\n", a, a, b, b, c, c);
+    }
+    fclose(fp);
+    return GRT_OK;
+}
+
 } // extern "C"

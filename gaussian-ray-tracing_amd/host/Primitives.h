@@ -1,6 +1,6 @@
 // Primitives.h — reflective mesh primitives (reference src/geometry/Primitives.h:13-65, .cpp:6-216):
-// procedural plane / UV sphere and an OBJ loader (tinyobjloader is not vendored; a minimal reader is
-// written here) with the reference's Y flip (Primitives.cpp:175,179).
+// procedural plane / UV sphere and an OBJ loader with the reference's Y flip (Primitives.cpp:175,179).  The geometry
+// comes from the C ABI (grt_host_primitive_*, grt_host_obj_*: csrc/grt_host.cpp); this class keeps the bookkeeping.
 #pragma once
 #include <cstddef>
 #include <string>
@@ -78,6 +78,8 @@ public:
 
 private:
     Mat4 getInitialTransform(float3 position) { return Mat4::translate(position); } // rotations 0, scale 1
+    Primitive registerPrimitive(Primitive p, const char* type, size_t& counter, float3 position);
+    Primitive createProcedural(int kind, const char* type, size_t& counter, float3 position);
 
     std::vector<Primitive> m_primitives;
     size_t numberOfMesh = 0, numberOfPlane = 0, numberOfSphere = 0, numberOfLoaded = 0;

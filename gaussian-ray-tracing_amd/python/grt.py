@@ -58,6 +58,7 @@ EXPORTS = [
     "grt_set_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_render_rays", "grt_sync",
     "grt_get_counters", "grt_last_kernel_ms", "grt_host_activate", "grt_host_uvw_frame", "grt_host_synth_scene",
     "grt_host_ply_count", "grt_host_ply_read", "grt_host_ply_write", "grt_host_last_error",
+    "grt_host_primitive_counts", "grt_host_primitive_fill", "grt_host_obj_count", "grt_host_obj_read", "grt_host_obj_write",
 ]
 
 _lib = None
@@ -103,6 +104,11 @@ def lib():
         L.grt_host_ply_read.argtypes = [C.c_char_p, u64] + [vp] * 6
         L.grt_host_ply_write.argtypes = [C.c_char_p, u64] + [vp] * 6
         L.grt_host_last_error.restype = C.c_char_p
+        L.grt_host_primitive_counts.argtypes = [C.c_int, C.POINTER(u32), C.POINTER(u32)]
+        L.grt_host_primitive_fill.argtypes = [C.c_int, vp, vp, vp]
+        L.grt_host_obj_count.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32)]
+        L.grt_host_obj_read.argtypes = [C.c_char_p, u32, vp, vp, vp]
+        L.grt_host_obj_write.argtypes = [C.c_char_p, u32, vp, vp, u32, vp]
         _lib = L
     return _lib
 
@@ -192,8 +198,39 @@ def gaussian_center(pos):
     return c
 
 
+PRIM_PLANE, PRIM_SPHERE = 0, 1
+
+
+def primitive_mesh(kind, center=(0.0, 0.0, 0.0)):
+    """The reference's procedural plane / sphere (src/geometry/Primitives.cpp:6-140) placed by translate(center),
+    from the C ABI (the same arrays the C++ facade's createPlane/createSphere hold): (verts, normals, faces)."""
+    nv, nf = C.c_uint32(), C.c_uint32()
+    _host_check(lib().grt_host_primitive_counts(kind, C.byref(nv), C.byref(nf)))
+    v = np.zeros((nv.value, 3), np.float32); n = np.zeros((nv.value, 3), np.float32); f = np.zeros((nf.value, 3), np.uint32)
+    _host_check(lib().grt_host_primitive_fill(kind, _p(v), _p(n), _p(f)))
+    c = np.asarray(center, np.float32)
+    return (v if not c.any() else (v + c[None]).astype(np.float32)), n, f  # (-0.0 + 0.0 would lose the sign bit)
+
+
+def load_obj(path, center=(0.0, 0.0, 0.0)):
+    """Primitives::createLoadMesh (src/geometry/Primitives.cpp:142-202): un-indexed soup, Y flipped, translate(center)."""
+    nv, nf = C.c_uint32(), C.c_uint32()
+    _host_check(lib().grt_host_obj_count(path.encode(), C.byref(nv), C.byref(nf)))
+    v = np.zeros((nv.value, 3), np.float32); n = np.zeros((nv.value, 3), np.float32); f = np.zeros(nv.value, np.uint32)
+    _host_check(lib().grt_host_obj_read(path.encode(), nv.value, _p(v), _p(n), _p(f)))
+    return (v + np.asarray(center, np.float32)[None]).astype(np.float32), n, f.reshape(-1, 3)
+
+
+def write_obj(path, verts, normals, faces):
+    v = np.ascontiguousarray(verts, np.float32); n = np.ascontiguousarray(normals, np.float32)
+    f = np.ascontiguousarray(faces, np.uint32)
+    _host_check(lib().grt_host_obj_write(path.encode(), len(v), _p(v), _p(n), len(f), _p(f)))
+
+
 def sphere_mesh(center, radius=0.3, tess_u=180, tess_v=90):
-    """Primitives::createSphere (src/geometry/Primitives.cpp:63-140) placed by translate(center)."""
+    """UV sphere with the reference's construction (src/geometry/Primitives.cpp:63-140) at any tessellation, placed by
+    translate(center) — numpy formulation for the small test meshes; primitive_mesh(PRIM_SPHERE) is the reference's
+    180 x 90 sphere itself."""
     f32 = np.float32
     phi_step = f32(2.0) * f32(np.pi) / f32(tess_u)
     theta_step = f32(np.pi) / f32(tess_v - 1)

@@ -22,7 +22,8 @@
  *   grt_sync                      CUDA_SYNC_CHECK()                        src/GaussianTracer.cpp:537
  *   grt_host_*                    host-side pieces the facade shares with ctypes users:
  *                                 GaussianData::parse (src/GaussianData.cpp:25-132), Camera::UVWFrame
- *                                 (src/Camera.cpp:3-13), Primitives (src/geometry/Primitives.cpp:6-216)
+ *                                 (src/Camera.cpp:3-13), grt_host_primitive_* / grt_host_obj_* = Primitives
+ *                                 (src/geometry/Primitives.cpp:6-216)
  *
  * Ownership: the library owns every device allocation it makes; the caller owns output buffers;
  * host input arrays are borrowed for the duration of the call only.  A context is bound to one
@@ -187,6 +188,18 @@ GRT_API int grt_host_ply_read(const char* path, uint64_t n, float* pos, float* f
                               float* opacity_logit, float* log_scale, float* rot);
 GRT_API int grt_host_ply_write(const char* path, uint64_t n, const float* pos, const float* f_dc, const float* f_rest,
                                const float* opacity_logit, const float* log_scale, const float* rot);
+/* Procedural primitives of the reference (src/geometry/Primitives.cpp:6-140) at the origin: verts[nv][3],
+ * normals[nv][3], faces[nf][3].  Two-call pattern: counts, then fill. */
+enum { GRT_PRIM_PLANE = 0, GRT_PRIM_SPHERE = 1 };
+GRT_API int grt_host_primitive_counts(int kind, uint32_t* nv, uint32_t* nf);
+GRT_API int grt_host_primitive_fill(int kind, float* verts, float* normals, uint32_t* faces);
+/* OBJ -> un-indexed triangle soup (one vertex per face corner, nf = nv / 3) with the reference's Y flip of positions
+ * and normals (src/geometry/Primitives.cpp:142-202).  faces is [nv] = 0..nv-1.  grt_host_obj_write writes
+ * "f a//a b//b c//c" with %.9g coordinates (fp32 round-trips). */
+GRT_API int grt_host_obj_count(const char* path, uint32_t* nv, uint32_t* nf);
+GRT_API int grt_host_obj_read(const char* path, uint32_t nv, float* verts, float* normals, uint32_t* faces);
+GRT_API int grt_host_obj_write(const char* path, uint32_t nv, const float* verts, const float* normals, uint32_t nf,
+                               const uint32_t* faces);
 GRT_API const char* grt_host_last_error(void);
 
 #ifdef __cplusplus

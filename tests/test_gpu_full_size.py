@@ -95,3 +95,53 @@ def test_c5_full_size_fisheye_kernel_and_shard_independence():
         gathered.append(buf)
     assert (tiles.assemble(gathered, W, H, 32) == u8).all()
     tr.close()
+
+
+def test_c4_full_size_mirror_sphere_through_the_obj_path(tmp_path):
+    """BASELINE config C4: the 1 M-Gaussian scene (seed 3) at 1920x1080 with the reference's procedural sphere
+    (src/geometry/Primitives.cpp:63-140) written once as OBJ with normals and loaded through the OBJ path (Y flip,
+    Primitives.cpp:175,179; un-indexed soup), placed at 0.25 lookat + 0.75 eye (src/GaussianTracer.cpp:630-638),
+    MIRROR, bounce cap 2.  The default pipeline (tile kernel + wavefront bounces), the streaming-kernel pipeline and,
+    on windows with mirror pixels, the per-lane megakernel agree bit for bit; the oracle is run on sampled windows
+    inside, at the rim of and outside the sphere."""
+    W, H = 1920, 1080
+    acts, p, sc, op, center = make_scene(3, 1_000_000, W, H, mesh_type=grt.MIRROR, max_bounces=2)
+    v, n, f = grt.primitive_mesh(grt.PRIM_SPHERE)
+    flip = np.float32([1, -1, 1])
+    path = str(tmp_path / "sphere.obj")
+    grt.write_obj(path, v * flip, n * flip, f)  # the loader flips Y back
+    pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+    mv, mn, mf = grt.load_obj(path, center=pos)
+    assert len(mv) == 3 * len(f) and (mv == (v[f.reshape(-1)] + pos[None]).astype(np.float32)).all() and (mn == n[f.reshape(-1)]).all()
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_meshes([(mv, mn, mf)])
+    sc.set_mesh(mv, mn, mf)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    u8, f32 = u8.clone(), f32.clone()
+    assert cnt["segments"] > 1.2 * cnt["rays"] and cnt["stall_exits"] == 0  # secondary segments exist
+    for _ in range(2):  # steady state (cost-ordered launch) writes the same frame
+        a8, af = tr.render(p, want_f32=True)
+        assert (a8 == u8).all() and (af == f32).all()
+    tr.set_option(grt.OPT_KERNEL, 3)
+    a8, af = tr.render(p, want_f32=True)
+    assert (a8 == u8).all() and (af == f32).all()
+    tr.set_option(grt.OPT_KERNEL, 1)
+    for win in ((896, 476, 1024, 604), (560, 440, 688, 568)):  # sphere centre; its left rim
+        x0, y0, x1, y1 = win
+        w8 = torch.zeros_like(u8); wf = torch.zeros_like(f32)
+        tr.render(p, window=win, out_u8=w8, out_f32=wf)
+        assert (w8[y0:y1, x0:x1] == u8[y0:y1, x0:x1]).all() and (wf[y0:y1, x0:x1] == f32[y0:y1, x0:x1]).all(), win
+    tr.set_option(grt.OPT_KERNEL, 0)
+    mirror_segments = 0
+    for (x0, y0, x1, y1) in [(952, 532, 968, 548), (700, 500, 716, 516), (1180, 640, 1196, 656), (600, 300, 616, 316),
+                             (560, 532, 576, 548), (40, 40, 56, 56)]:
+        ref_u8, ref_f32, rc = sc.render(op, window=(x0, y0, x1, y1), threads=8)
+        compare(f32[y0:y1, x0:x1], ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1])
+        mirror_segments += rc["segments"] - rc["rays"]
+    assert mirror_segments > 3 * 256  # most sampled windows look into the mirror
+    tr.close()
+    sc.close()

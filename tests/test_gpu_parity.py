@@ -1,5 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
-inputs.  Tolerances (north star): radiance max |diff| <= 1e-4 per channel; 8-bit output exact or +-1."""
+inputs.  Tolerances (north star): radiance max |diff| <= 1e-4 per channel; 8-bit output EQUAL to the oracle's except
+within that tolerance of a quantisation step (see compare())."""
 import json
 import os
 
@@ -28,16 +29,24 @@ def tr(request):
     t.close()
 
 
-def compare(gpu_f32, ref_f32, gpu_u8=None, ref_u8=None, tol=TOL, max_outlier_frac=0.0):
+def compare(gpu_f32, ref_f32, gpu_u8=None, ref_u8=None, tol=TOL, max_outlier_frac=0.0, max_outlier=0.0):
+    """Radiance within `tol` on every pixel (or on all but `max_outlier_frac` of them, each of which is still within
+    `max_outlier`).  The 8-bit frame must EQUAL the oracle's, except on pixels whose radiance lies within `tol` of a
+    quantisation step (x * 256 within tol * 256 of an integer, where a difference below the radiance tolerance may
+    legitimately change the level by one) and on the radiance outliers."""
     g = gpu_f32.cpu().numpy() if hasattr(gpu_f32, "cpu") else gpu_f32
     d = np.abs(g - ref_f32)
     bad = (d > tol).any(-1)
     frac = bad.mean()
     assert frac <= max_outlier_frac, f"max diff {d.max():.3e}, {bad.sum()} px over {tol}"
+    if bad.any():
+        assert d[bad].max() <= max_outlier, f"outlier of {d[bad].max():.3e} (bound {max_outlier})"
     if gpu_u8 is not None:
         du = np.abs(gpu_u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
-        if max_outlier_frac == 0.0:
-            assert du.max() <= 1
+        x = np.clip(ref_f32.astype(np.float64), 0.0, 1.0) * 256.0
+        near_step = np.abs(x - np.round(x)) <= tol * 256.0
+        ok = (du == 0) | ((du == 1) & near_step) | bad[..., None]
+        assert ok.all(), f"{(~ok).sum()} 8-bit values differ away from a quantisation step (max {du.max()})"
     return d.max()
 
 
@@ -71,7 +80,7 @@ def test_c1_10k_256x256_pinhole(tr):
     tr.set_option(grt.OPT_COUNTERS, 0)
     ref_u8, ref_f32, rc = sc.render(op)
     compare(f32, ref_f32, u8, ref_u8)
-    assert cnt["rays"] == rc["rays"] == 256 * 256
+    assert cnt["rays"] == rc["rays"] == 256 * 256 and cnt["stall_exits"] == 0
     assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
     if tr.kernel_variant not in (0, 3):  # the streaming / tile kernels replace the k = 7 rounds by (mostly) one pass
         assert cnt["rounds"] == rc["rounds"] or abs(cnt["rounds"] - rc["rounds"]) <= 1e-4 * rc["rounds"]
@@ -97,10 +106,14 @@ def test_dense_large_proxies_many_rounds(tr):
     """Large, overlapping proxies: dozens of k-buffer rounds per ray."""
     acts, p, sc, op, _ = make_scene(6, 1500, 64, 64, scale_boost=1.5)
     tr.upload(acts)
+    tr.set_option(grt.OPT_COUNTERS, 1)
     u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
     ref_u8, ref_f32, rc = sc.render(op)
     compare(f32, ref_f32, u8, ref_u8)
     assert rc["rounds"] > 3 * rc["rays"]
+    assert cnt["stall_exits"] == 0 and abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
 
 
 def test_fisheye(tr):
@@ -113,7 +126,7 @@ def test_fisheye(tr):
     cnt = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
     ref_u8, ref_f32, rc = sc.render(op)
-    compare(f32, ref_f32, u8, ref_u8, max_outlier_frac=2e-4)
+    compare(f32, ref_f32, u8, ref_u8, max_outlier_frac=2e-4, max_outlier=0.08)
     assert cnt["rays"] == rc["rays"] < 128 * 96
     g = f32.cpu().numpy()
     assert (g[0, 0] == 0).all() and (u8.cpu().numpy()[0, 0] == 0).all()  # r > 1 => black (decision vii)
@@ -322,6 +335,7 @@ def test_coincident_gaussians_deep_overlap(tr):
     compare(f32, ref_f32, u8, ref_u8)
     assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
     assert rc["hit_evals"] > 20 * rc["rays"]
+    assert cnt["stall_exits"] == 0  # no lane was given up on with transmittance left
     sc.close()
 
 

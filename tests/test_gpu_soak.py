@@ -26,7 +26,13 @@ def test_moving_camera_soak():
         eye = np.float32([r * np.sin(ang), 0.6 * np.sin(2 * ang), r * np.cos(ang)])
         fisheye = i % 37 == 0
         p = grt.default_params(W, H, center, eye=eye, fovy=60.0 if i % 50 else 100.0, fisheye=fisheye)
+        count = i % 10 == 5  # every tenth frame on the instrumented kernel: no lane may be given up on
+        if count:
+            tr.set_option(grt.OPT_COUNTERS, 1)
         u8, f32 = tr.render(p, want_f32=True)
+        if count:
+            assert tr.counters()["stall_exits"] == 0, i
+            tr.set_option(grt.OPT_COUNTERS, 0)
         if i % 20 == 0:
             a8, af = tw.render(p, want_f32=True)
             assert (a8 == u8).all() and (af == f32).all(), i

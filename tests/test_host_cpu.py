@@ -195,3 +195,48 @@ def test_generated_slot_macros_are_current():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussian-ray-tracing_amd", "csrc")
     out = subprocess.run([sys.executable, os.path.join(d, "gen_slots.py")], capture_output=True, text=True, check=True).stdout
     assert out == open(os.path.join(d, "grt_slots_gen.inc")).read()
+
+
+def _fnv(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def test_procedural_primitives_are_unchanged():
+    """grt_host_primitive_* (table-driven lattice) produce, bit for bit, the arrays the round-1 facade produced by
+    following src/geometry/Primitives.cpp:6-140 statement by statement (FNV-1a of the raw bytes recorded then)."""
+    v, n, f = grt.primitive_mesh(grt.PRIM_PLANE)
+    assert (v.shape, f.shape) == ((4, 3), (2, 3))
+    assert (_fnv(v), _fnv(n), _fnv(f)) == ("7a2c5c8c355ac993", "559fdd29b636fee3", "5e76009c85122600")
+    v, n, f = grt.primitive_mesh(grt.PRIM_SPHERE)
+    assert (v.shape, f.shape) == ((16290, 3), (32040, 3))
+    assert (_fnv(v), _fnv(n), _fnv(f)) == ("644ab7773a63ff81", "1384e9db3e63bbe6", "45d53d77f94efe52")
+    # unit normals, radius 0.3, south pole first (theta = 0 -> +y)
+    assert np.abs(np.linalg.norm(n, axis=1) - 1).max() < 1e-6 and np.abs(np.linalg.norm(v, axis=1) - 0.3).max() < 1e-6
+    assert v[0, 1] == np.float32(0.3)
+    # the numpy formulation used for the small test meshes agrees to rounding
+    v2, n2, f2 = grt.sphere_mesh((0, 0, 0))
+    assert (f2 == f).all() and np.abs(v2 - v).max() < 1e-6
+
+
+def test_obj_round_trip_flips_y_and_unindexes(tmp_path):
+    """Primitives::createLoadMesh (src/geometry/Primitives.cpp:142-202): one vertex per face corner in file order, Y of
+    positions and normals negated; polygons fan-triangulated; a corner without a normal is an error."""
+    v, n, f = grt.primitive_mesh(grt.PRIM_SPHERE)
+    q = str(tmp_path / "s.obj")
+    grt.write_obj(q, v, n, f)
+    mv, mn, mf = grt.load_obj(q, center=(0.5, 0.0, -1.0))
+    flip = np.float32([1, -1, 1])
+    assert (mf == np.arange(3 * len(f), dtype=np.uint32).reshape(-1, 3)).all()
+    assert (mv == (v[f.reshape(-1)] * flip + np.float32([0.5, 0.0, -1.0])).astype(np.float32)).all()
+    assert (mn == n[f.reshape(-1)] * flip).all()
+    quad = str(tmp_path / "quad.obj")
+    open(quad, "w").write("v 0 0 0\nv 1 0 0\nv 1 2 0\nv 0 2 0\nvn 0 0 1\nf 1//1 2//1 3//1 -1//-1\n")
+    qv, qn, qf = grt.load_obj(quad)
+    assert qv.tolist() == [[0, 0, 0], [1, 0, 0], [1, -2, 0], [0, 0, 0], [1, -2, 0], [0, -2, 0]] and (qn == [0, 0, 1]).all()
+    bad = str(tmp_path / "bad.obj")
+    open(bad, "w").write("v 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3\n")
+    with pytest.raises(grt.GrtError, match="normal"):
+        grt.load_obj(bad)
