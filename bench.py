@@ -18,13 +18,18 @@ with its own context (its own scheduling feedback and buffers), HIP stream and o
 frame overlaps the bulk of the next ones, as a viewer that double-buffers its display would run it.  Every one
 of the K timed steps is still a complete frame (render, gather, un-permute) and all of them finish inside the timed
 region.  Default: D = 1 on one GPU (each frame is synchronised, like the reference's render(); this is the run
-the roofline and the rocprof summaries refer to), 4 on 2-4 GPUs, 8 on 8; `config.latency_ms_per_frame` is the
-synchronous single-frame time of the same rank layout.
+the roofline and the rocprof summaries refer to), 4 on 2-4 GPUs, 8 on 8.  So that a scaling curve compares like
+with like, EVERY run reports both figures next to `value`: `config.value_sync` (D = 1, every frame synchronised)
+and `config.value_pipelined` (D = 4, or 8 from 8 GPUs on), each over its own K timed frames.
+
+The step machinery (frame slots, tile split, gather, un-permute) is class FrameLoop: bench.py drives it with the HIP
+library over RCCL, tests/test_multi_rank_cpu.py drives the same class with the CPU oracle over gloo.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,34 +40,112 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per frame 
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: (seed, n_gaussians, width, height, fisheye, mesh, max_bounces)   — BASELINE.json configs
-    "C1": (1, 10_000, 256, 256, False, False, 32),
-    "C2": (2, 100_000, 1280, 720, False, False, 32),
-    "C3": (3, 1_000_000, 1920, 1080, False, False, 32),
-    "C4": (3, 1_000_000, 1920, 1080, False, True, 2),
-    "C5": (5, 3_000_000, 3840, 2160, True, False, 32),
+    # name: (seed, n_gaussians, width, height, fisheye, mesh, max_bounces, per-axis log-scale noise)   — BASELINE.json configs
+    "C1": (1, 10_000, 256, 256, False, False, 32, 0.0),
+    "C2": (2, 100_000, 1280, 720, False, False, 32, 0.0),
+    "C3": (3, 1_000_000, 1920, 1080, False, False, 32, 0.0),
+    # C3 with trained-scene-like anisotropy: every axis' log-scale gets N(0, 1.6^2) on top (needles, pancakes)
+    "C3a": (3, 1_000_000, 1920, 1080, False, False, 32, 1.6),
+    "C4": (3, 1_000_000, 1920, 1080, False, True, 2, 0.0),
+    "C5": (5, 3_000_000, 3840, 2160, True, False, 32, 0.0),
 }
 TILE = 32
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+TRAFFIC_FILE = os.path.join("profiles", "traffic.json")
 
 
-def kernel_name(variant, with_mesh, n_proxies, sh_degree):
-    """Which kernel grt_render dispatches to (csrc/grt_render.hip: launch_render)."""
+def kernel_name(variant, with_mesh, sh_degree, leaf_max=4):
+    """Which kernel grt_render dispatches the Gaussian segment of camera rays to (csrc/grt_render.hip: launch_render)."""
     sh = "true" if sh_degree > 0 else "false"
+    mesh = "true" if with_mesh else "false"
     if variant == 1:
         return "grt::k_render<false>"
     if variant == 2 and not with_mesh:
         return f"grt::k_render_wave<false, {sh}>"
-    return f"grt::k_render_stream<false, {sh}, {'true' if with_mesh else 'false'}>"
+    if variant in (0, 5) and leaf_max <= 4:
+        return f"grt::k_render_tile<false, {sh}, {mesh}>"
+    return f"grt::k_render_stream<false, {sh}, {mesh}>"
 
 
 def algorithmic_bytes(cnt, pixels, sh_degree, float_out=False):
-    """Bytes the kernel's algorithm needs per frame: every BVH node / proxy record at the
-    granularity the kernel fetches it — once per WAVE, by scalar load: a 4-wide node is 128 B, a proxy record
-    64 B (mu/A/s/opacity/id) + its 16-B eye record; the counter is in 16-B units — plus, for every consumed
-    hit, its colour (16 B at degree 0, 192 B of SH above), and 3 B per pixel (+12 B float)."""
+    """Bytes the kernel's algorithm needs per frame: every BVH child box / proxy record at the
+    granularity the kernel fetches it (the counter is in 16-B units) — tile kernel: a child box is 32 B per LANE that
+    tests it, a proxy record + its eye record 128 B per WAVE; streaming kernel: a 4-wide node 128 B, a proxy record +
+    eye record 80 B, per wave — plus, for every consumed hit, its colour (16 B at degree 0, 192 B of SH above), and
+    3 B per pixel (+12 B float)."""
     b_col = 16 if sh_degree == 0 else 192
     return cnt["rec_fetches"] * 16 + cnt["hit_evals"] * b_col + pixels * (3 + (12 if float_out else 0))
+
+
+class FrameLoop:
+    """The per-frame work of one rank: frame i runs in slot i % D (own stream / buffers); every rank renders its
+    round-robin tiles into the slot's compact buffer, ONE gather per frame brings the buffers to rank 0, which
+    un-permutes them into the slot's frame.  `render_full(slot, frame)` / `render_tiles(slot, first, stride, count,
+    out)` do the rendering (HIP library in bench.py, the CPU oracle in the gloo test); `dist` is torch.distributed or
+    None; `local_gather` replaces the collective by a local copy (one-rank emulation on one GPU)."""
+
+    def __init__(self, torch, tiles, width, height, world, rank, slots, device, render_full, render_tiles, dist=None,
+                 local_gather=False, streams=None):
+        self.torch, self.tiles, self.W, self.H = torch, tiles, width, height
+        self.world, self.rank, self.D, self.dist, self.local = world, rank, slots, dist, local_gather
+        self.render_full, self.render_tiles = render_full, render_tiles
+        tx, ty = tiles.grid(width, height, TILE)
+        self.n_tiles = tx * ty
+        _, _, self.my_cnt, self.max_cnt = tiles.my_tiles(self.n_tiles, world, rank)
+        self.frames = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.mines = self.gathereds = None
+        if world > 1:
+            self.mines = [torch.zeros((self.max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
+            root = rank == 0 or local_gather
+            self.gathereds = [[torch.zeros_like(self.mines[0]) for _ in range(world)] if root else None for _ in range(slots)]
+        self.streams = streams
+
+    def step(self, i=0):
+        k = i % self.D
+        ctx = self.torch.cuda.stream(self.streams[k]) if self.streams else _Null()
+        with ctx:
+            if self.world == 1:
+                self.render_full(k, self.frames[k])
+                return
+            self.render_tiles(k, self.rank, self.world, self.my_cnt, self.mines[k])
+            if self.local:
+                self.gathereds[k][self.rank].copy_(self.mines[k])  # stands in for the collective
+            else:
+                # RCCL: 7 peers -> 7 distinct xGMI links into rank 0, <= 0.8 MB each at 1080p
+                self.dist.gather(self.mines[k], self.gathereds[k], dst=0)
+            if self.rank == 0 or self.local:
+                self.frames[k].copy_(self.tiles.assemble(self.gathereds[k], self.W, self.H, TILE))
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def build_scene(grt, workload):
+    """Synthetic inputs of one BASELINE config: raw PLY columns -> activated arrays, camera, mesh."""
+    seed, n, W, H, fisheye, with_mesh, max_bounces, aniso = WORKLOADS[workload]
+    raw = grt.synth_scene(seed, n)
+    if aniso:
+        rng = np.random.default_rng(seed + 1000)
+        raw["scale"] = (raw["scale"] + rng.normal(0.0, aniso, size=raw["scale"].shape)).astype(np.float32)
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    mesh = None
+    if with_mesh:
+        # the reference's procedural sphere written ONCE as OBJ with normals and loaded through the OBJ path (Y flip,
+        # src/geometry/Primitives.cpp:175,179), placed at 0.25 lookat + 0.75 eye (src/GaussianTracer.cpp:630-638)
+        v, nrm, f = grt.primitive_mesh(grt.PRIM_SPHERE)
+        flip = np.float32([1, -1, 1])
+        pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sphere.obj")
+            grt.write_obj(path, v * flip, nrm * flip, f)
+            mesh = grt.load_obj(path, center=pos)
+    return acts, center, mesh
 
 
 def main():
@@ -73,6 +156,7 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (cold frame, orbit, the other pipelining depth)")
     ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
     ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -80,7 +164,7 @@ def main():
                          "un-permute; the collective is replaced by a local copy) - per-rank time without N GPUs")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="which rank to emulate (default N // 2)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="frames in flight per rank (0 = auto: 1 on one GPU, 4 on 2-4 GPUs, 8 on 8+)")
+                    help="frames in flight per rank for `value` (0 = auto: 1 on one GPU, 4 on 2-4 GPUs, 8 on 8+)")
     args = ap.parse_args()
 
     import torch
@@ -109,20 +193,18 @@ def main():
     emul = args.emulate_ranks if (args.emulate_ranks > 1 and world == 1) else 0
     t_world, t_rank = (emul, (args.emulate_rank if args.emulate_rank >= 0 else emul // 2)) if emul else (world, rank)
 
-    seed, n, W, H, fisheye, with_mesh, max_bounces = WORKLOADS[args.workload]
-    raw = grt.synth_scene(seed, n)
-    acts = grt.activate(raw)
-    center = grt.gaussian_center(acts["pos"])
+    seed, n, W, H, fisheye, with_mesh, max_bounces, aniso = WORKLOADS[args.workload]
+    acts, center, mesh = build_scene(grt, args.workload)
     p = grt.default_params(W, H, center, sh_degree=args.sh_degree, fisheye=fisheye, mesh_type=grt.MIRROR,
                            max_bounces=max_bounces)
-    D = args.inflight if args.inflight > 0 else (1 if t_world == 1 else (8 if t_world >= 8 else 4))
-    mesh = None
-    if with_mesh:
-        pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)  # src/GaussianTracer.cpp:630-638
-        mesh = grt.sphere_mesh(pos)
+    D_pipe = 8 if t_world >= 8 else 4
+    D = args.inflight if args.inflight > 0 else (1 if t_world == 1 else D_pipe)
+    extra = not args.no_extra_legs
+    D_other = (D_pipe if D == 1 else 1) if extra else 0  # the other pipelining depth, reported alongside
+    n_ctx = max(D, D_other)
     t0 = time.time()
     trs = []
-    for _ in range(D):  # one context per frame slot (the scene is a few hundred MB: replicated per slot)
+    for _ in range(n_ctx):  # one context per frame slot (the scene is a few hundred MB: replicated per slot)
         t = grt.Tracer(local_rank)
         t.set_option(grt.OPT_KERNEL, args.kernel)
         t.upload(acts)
@@ -130,63 +212,52 @@ def main():
             t.set_meshes([mesh])
         trs.append(t)
     tr = trs[0]
-    setup_s = (time.time() - t0) / D
+    setup_s = (time.time() - t0) / n_ctx
     info = tr.bvh_info()
 
-    # ---- work split ----
-    tx, ty = tiles.grid(W, H, TILE)
-    n_tiles = tx * ty
-    _, _, my_cnt, max_cnt = tiles.my_tiles(n_tiles, t_world, t_rank)
-    frames = [torch.zeros((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(D)]
-    frame = frames[0]
-    if t_world > 1:
-        mines = [torch.zeros((max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=dev) for _ in range(D)]
-        mine = mines[0]
-        gathereds = [[torch.zeros_like(mine) for _ in range(t_world)] if (rank == 0 or emul) else None for _ in range(D)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(D)] if D > 1 else [torch.cuda.current_stream()]
+    def make_loop(depth):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else None
+        return FrameLoop(torch, tiles, W, H, t_world, t_rank, depth, dev,
+                         render_full=lambda k, frame: trs[k].render(p, out_u8=frame, want_u8=True),
+                         render_tiles=lambda k, first, stride, cnt, out: trs[k].render_tiles(p, TILE, TILE, first, stride, cnt, out_u8=out),
+                         dist=dist, local_gather=bool(emul), streams=streams)
 
-    def step(i=0):
-        k = i % D
-        with torch.cuda.stream(streams[k]):
-            if t_world == 1:
-                trs[k].render(p, out_u8=frames[k], want_u8=True)
-            else:
-                trs[k].render_tiles(p, TILE, TILE, t_rank, t_world, my_cnt, out_u8=mines[k])
-                if emul:
-                    gathereds[k][t_rank].copy_(mines[k])  # stands in for the collective
-                else:
-                    dist.gather(mines[k], gathereds[k], dst=0)  # RCCL: 7 peers -> 7 distinct xGMI links into rank 0, <= 0.8 MB each
-                if rank == 0:
-                    frames[k].copy_(tiles.assemble(gathereds[k], W, H, TILE))
+    loop = make_loop(D)
+    frame = loop.frames[0]
+    my_cnt = loop.my_cnt
+
+    def one_frame(t=tr, q=p):
+        if t_world == 1:
+            t.render(q, out_u8=frame, want_u8=True)
+        else:
+            t.render_tiles(q, TILE, TILE, t_rank, t_world, my_cnt, out_u8=loop.mines[0])
 
     # ---- instrumented frame (outside the timed region): counters for rays and algorithmic bytes ----
     tr.set_option(grt.OPT_COUNTERS, 1)
-    if t_world == 1:
-        tr.render(p, out_u8=frame, want_u8=True)
-    else:
-        tr.render_tiles(p, TILE, TILE, t_rank, t_world, my_cnt, out_u8=mine)
+    one_frame()
     cnt = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
-    # first frame without scheduling feedback (what a cold start / a camera cut costs), for the record
-    tr.set_option(grt.OPT_FEEDBACK, 0)
-    step_cold = (lambda: tr.render(p, out_u8=frame, want_u8=True)) if t_world == 1 else \
-        (lambda: tr.render_tiles(p, TILE, TILE, t_rank, t_world, my_cnt, out_u8=mine))
-    step_cold(); step_cold()
-    cold_ms = tr.last_kernel_ms()
-    tr.set_option(grt.OPT_FEEDBACK, 1)
-    # a moving camera: the eye records (one pass over the particles) are rebuilt inside the timed kernel bracket
-    moving_ms = None
-    if t_world == 1:
-        import copy
+    cold_ms = orbit_ms = None
+    if extra:
+        # a frame without scheduling feedback (what a cold start / a camera cut costs), for the record
+        tr.set_option(grt.OPT_FEEDBACK, 0)
+        one_frame(); one_frame()
+        cold_ms = tr.last_kernel_ms()
+        tr.set_option(grt.OPT_FEEDBACK, 1)
+        # a MOVING camera: the eye orbits the look-at point by 1.5 degrees per frame (the per-eye records are rebuilt
+        # and the previous frame's tile costs order a slightly different frame); median over the last 8 of 10 frames
         mm = []
-        for i in range(6):
-            q = copy.copy(p)
-            q.eye[0] = p.eye[0] + 1e-4 * (i + 1)
-            tr.render(q, out_u8=frame, want_u8=True)
+        eye0 = np.float32(list(p.eye)) - center
+        for i in range(10):
+            ang = np.deg2rad(1.5 * (i + 1))
+            eye = center + np.float32([eye0[0] * np.cos(ang) + eye0[2] * np.sin(ang), eye0[1], -eye0[0] * np.sin(ang) + eye0[2] * np.cos(ang)])
+            q = grt.default_params(W, H, center, sh_degree=args.sh_degree, fisheye=fisheye, mesh_type=grt.MIRROR,
+                                   max_bounces=max_bounces, eye=tuple(float(x) for x in eye))
+            one_frame(q=q)
             mm.append(tr.last_kernel_ms())
-        moving_ms = float(np.median(mm[2:]))
-        tr.render(p, out_u8=frame, want_u8=True)
-    names = ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests", "rec_fetches")
+        orbit_ms = float(np.median(mm[2:]))
+        one_frame(); one_frame()
+    names = ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests", "rec_fetches", "stall_exits")
     cnt_t = torch.tensor([cnt[k] for k in names], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(cnt_t)
@@ -195,71 +266,86 @@ def main():
         tot = {k: v * t_world for k, v in tot.items()}
     rays_per_frame = tot["segments"]  # primary rays + each secondary segment
 
-    # every frame slot gets its scheduling feedback before anything is timed (set-up, like the frames above);
-    # with several frames in flight the big-window split (a second stream per context) is left out
-    latency_ms = None
-    if D > 1:
-        for t in trs:
-            t.set_option(grt.OPT_FEEDBACK, 3)
-        for i in range(2 * D):
-            step(i)
+    def timed(lp, steps, warmup):
+        """K frames of one FrameLoop between barrier + synchronize: (elapsed s, synchronous single-frame latency ms)."""
+        latency = None
+        if lp.D > 1:
+            for t in trs[:lp.D]:
+                t.set_option(grt.OPT_FEEDBACK, 3)  # several frames in flight: no big-window split (a second stream per context)
+            for i in range(2 * lp.D):
+                lp.step(i)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(5):  # synchronous single-frame time of this rank layout (slot 0)
+                torch.cuda.synchronize()
+                tl = time.perf_counter()
+                lp.step(0)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - tl) * 1e3)
+            latency = float(np.median(lat))
+        for i in range(warmup):
+            lp.step(i)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        # synchronous single-frame time of this rank layout (slot 0): the latency a frame has without the overlap
-        lat = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            tl = time.perf_counter()
-            step(0)
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - tl) * 1e3)
-        latency_ms = float(np.median(lat))
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kern_ms = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        if D == 1:
-            kern_ms.append(tr.last_kernel_ms())  # HIP events on the launch stream; syncs like the reference's render()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        kms = []
+        ts = time.perf_counter()
+        for i in range(steps):
+            lp.step(i)
+            if lp.D == 1:
+                kms.append(tr.last_kernel_ms())  # HIP events on the launch stream; syncs like the reference's render()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        for t in trs[:lp.D]:
+            t.set_option(grt.OPT_FEEDBACK, 1)
+        return el, latency, kms
+
+    elapsed, latency_ms, kern_ms = timed(loop, args.steps, args.warmup)
     if D > 1:
         # kernel duration for the roofline: synchronous launches of the same frame right after the timed region
         # (the launches inside it overlap each other, so their own durations are not launch durations)
         for _ in range(4):
-            step(0)
+            loop.step(0)
             kern_ms.append(trs[0].last_kernel_ms())
         kern_ms = kern_ms[1:]
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    other = None
+    if D_other:
+        lp2 = make_loop(D_other)
+        el2, lat2, _ = timed(lp2, args.steps, args.warmup)
+        other = (el2, lat2)
+        if latency_ms is None:
+            latency_ms = lat2
+    el = torch.tensor([elapsed, other[0] if other else 0.0], dtype=torch.float64, device=dev)
     km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed, elapsed_other = float(el[0].item()), float(el[1].item())
     kernel_ms = float(km.item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_per_frame * args.steps / elapsed / 1e6
-        # roofline of the dominant (only) kernel: this rank's launch
+        value_other = rays_per_frame * args.steps / elapsed_other / 1e6 if other else None
+        value_sync, value_pipe = (value, value_other) if D == 1 else (value_other, value)
+        # roofline of the dominant kernel: this rank's launch
         pix_mine = W * H if t_world == 1 else my_cnt * TILE * TILE
         b_alg = algorithmic_bytes(cnt, pix_mine, args.sh_degree)
         b_min = cnt["hit_evals"] * (44 + 12 * (args.sh_degree + 1) ** 2) + pix_mine * 3  # SURVEY §8(d) floor
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        valu = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic = valu = traffic_source = None
+        tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.workload}_sh{args.sh_degree}_k{args.kernel}_n{t_world}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
                 valu = tj.get(key, {}).get("valu")  # SQ counters of the same launch: what actually bounds the kernel
+                if traffic is not None or valu is not None:
+                    traffic_source = (f"{TRAFFIC_FILE} ['{key}']: rocprofv3 --pmc passes of this same command collected by "
+                                      f"profiles/collect.sh ({tj.get(key, {}).get('collected', 'date not recorded')}); NOT measured by this run")
             except Exception:
                 traffic = None
         out = {
@@ -268,28 +354,34 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n}-Gaussian synthetic 3DGS scene (seed {seed}), {W}x{H} "
                                    f"{'fisheye' if fisheye else 'pinhole'}, SH degree {args.sh_degree}"
-                                   f"{', reflective sphere mesh, <=2 bounces' if with_mesh else ', no mesh'}",
+                                   f"{', per-axis log-scale noise sigma %.1f (needles / pancakes)' % aniso if aniso else ''}"
+                                   f"{', reflective sphere (reference primitive, through the OBJ path), <= 2 bounces' if with_mesh else ', no mesh'}",
                        "tile": f"{TILE}x{TILE} round-robin over ranks, RCCL gather to rank 0" if t_world > 1 else "full frame, one launch",
                        "emulated_ranks": (f"rank {t_rank} of {t_world} on one GPU, no collective; value = this rank's rays x {t_world} / time"
                                           if emul else None),
                        "frames_in_flight": D,
+                       "value_sync": None if value_sync is None else round(value_sync, 3),
+                       "value_pipelined": None if value_pipe is None else round(value_pipe, 3),
+                       "pipelined_frames_in_flight": D if D > 1 else (D_other or None),
                        "latency_ms_per_frame": None if latency_ms is None else round(latency_ms, 4),
                        "rays_per_frame": rays_per_frame, "hit_evals_per_ray": round(tot["hit_evals"] / max(tot["segments"], 1), 2),
                        "rounds_per_ray": round(tot["rounds"] / max(tot["segments"], 1), 2),
                        "node_visits_per_ray": round(tot["node_visits"] / max(tot["segments"], 1), 1),
                        "proxy_tests_per_ray": round(tot["proxy_tests"] / max(tot["segments"], 1), 1),
                        "fetched_record_bytes_per_ray": round(16 * tot["rec_fetches"] / max(tot["segments"], 1), 1),
+                       "stall_exits": tot["stall_exits"],
                        "bvh_height": info["height"], "n_proxies": info["n_proxies"], "bvh_build_ms": round(info["build_ms"], 2),
                        "setup_s": round(setup_s, 2), "kernel_variant": args.kernel,
                        "scheduling": "8x8 tiles launched heaviest-first from the previous frame's per-tile cost "
-                                     "(steady state of an interactive viewer); kernel_ms_cold is one frame without it, "
-                                     "kernel_ms_moving_camera re-derives the per-eye records every frame",
-                       "kernel_ms_cold": round(cold_ms, 4),
-                       "kernel_ms_moving_camera": None if moving_ms is None else round(moving_ms, 4)},
+                                     "(steady state of an interactive viewer); kernel_ms_cold is one frame without it; "
+                                     "kernel_ms_orbit: the eye orbits the look-at point by 1.5 degrees per frame "
+                                     "(per-eye records rebuilt, last frame's costs order a different frame)",
+                       "kernel_ms_cold": None if cold_ms is None else round(cold_ms, 4),
+                       "kernel_ms_orbit": None if orbit_ms is None else round(orbit_ms, 4)},
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kernel_name(args.kernel, with_mesh, info["n_proxies"], args.sh_degree), "algorithmic_bytes_per_launch": int(b_alg),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name(args.kernel, with_mesh, args.sh_degree), "algorithmic_bytes_per_launch": int(b_alg),
                          "floor_bytes_per_launch": int(b_min),
                          "floor_frac": round(b_min / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "valu_issue": valu},
@@ -308,7 +400,8 @@ def main():
 
 def cpu_baseline(acts, p, mesh, W, H):
     """The CPU oracle (oracle/grt_oracle.c, kind 'port': the reference itself needs OptiX and cannot run on a
-    CPU) on a bounded sample of the same workload: the centred quarter-area crop of the same frame."""
+    CPU) on a bounded sample of the same workload: the whole frame up to 1080p, the centred quarter-area window of it
+    above (about 10-30 s of CPU work on the GPU box's 16 cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O

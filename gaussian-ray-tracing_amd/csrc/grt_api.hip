@@ -253,7 +253,7 @@ void grt_destroy(grt_ctx* c)
     (void)hipFree(c->d_erec);
     (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_cost); (void)hipFree(c->d_order);
+    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -287,6 +287,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_TILE_READY_MIN) { c->opt_tile_ready = std::min(64, std::max(1, value)); }
     else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
     else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
+    else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
@@ -521,18 +522,25 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
                              ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
     if (c->cost_cap < n_units) {
-        (void)hipFree(c->d_cost); (void)hipFree(c->d_order);
-        c->d_cost = c->d_order = nullptr;
+        (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
+        c->d_cost = c->d_order = c->d_cost_dil = nullptr;
         c->cost_cap = 0;
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * n_units));
+        CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     if (same) {
         const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
-        int rc = order_units_by_cost(c->d_cost, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
+        const uint32_t* cost_src = c->d_cost;
+        if (c->opt_cost_radius > 0 && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
+            int rcd = dilate_unit_costs(c->d_cost, c->d_cost_dil, a.nbx, a.nby, c->opt_cost_radius, s, &c->err);
+            if (rcd != GRT_OK) return rcd;
+            cost_src = c->d_cost_dil;
+        }
+        int rc = order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
                                      (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;

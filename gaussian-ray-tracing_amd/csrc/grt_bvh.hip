@@ -275,6 +275,41 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
     }
 }
 
+// Under a MOVING camera a heavy tile of the previous frame is a slightly different tile of this one: every 8x8 tile
+// takes the largest cost within `radius` tiles of itself, so the neighbourhood of last frame's heavy tiles starts
+// early too.  Units are (16x16 block, quadrant): block b = by * nbx + bx, quadrant q -> tile (2 bx + (q & 1), 2 by + (q >> 1)).
+__global__ void k_cost_dilate(const uint32_t* __restrict__ cost, uint32_t* __restrict__ out, uint32_t nbx, uint32_t nby, int radius)
+{
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nbx * nby * 4u) return;
+    const uint32_t b = u >> 2, q = u & 3u;
+    const int tx = (int)((b % nbx) * 2u + (q & 1u)), ty = (int)((b / nbx) * 2u + (q >> 1));
+    const int ntx = (int)nbx * 2, nty = (int)nby * 2;
+    uint32_t m = 0;
+    for (int dy = -radius; dy <= radius; dy++)
+        for (int dx = -radius; dx <= radius; dx++) {
+            const int x = tx + dx, y = ty + dy;
+            if (x < 0 || y < 0 || x >= ntx || y >= nty) continue;
+            const uint32_t v = cost[(((uint32_t)y >> 1) * nbx + ((uint32_t)x >> 1)) * 4u + (((uint32_t)y & 1u) << 1) + ((uint32_t)x & 1u)];
+            m = max(m, v);
+        }
+    out[u] = m;
+}
+
+int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,
+                      std::string* err)
+{
+    const uint32_t n = nbx * nby * 4u;
+    if (n == 0) return GRT_OK;
+    hipLaunchKernelGGL(k_cost_dilate, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_cost, d_out, nbx, nby, radius);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("dilate_unit_costs: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
                         uint32_t* d_n_heavy, hipStream_t stream, std::string* err)
 {

@@ -142,6 +142,9 @@ inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, i
 {
     return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4;
 }
+// per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)
+int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,
+                      std::string* err);
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
                         uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
@@ -191,7 +194,8 @@ struct grt_ctx {
     bool have_timing = false;
     // frame-to-frame scheduling feedback (grt_api.hip: do_launch)
     int opt_feedback = 1;
-    uint32_t *d_cost = nullptr, *d_order = nullptr;
+    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr;
+    int opt_cost_radius = 4; // tiles; 0 = off
     uint32_t cost_cap = 0;
     bool cost_valid = false;
     // wavefront buffers (allocated on first mesh frame)

@@ -27,10 +27,16 @@ def test_bench_json_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None
     assert d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["higher_is_better"] is True
-    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and d["config"]["frames_in_flight"] == 1
+    c = d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in c and c["frames_in_flight"] == 1
+    # both pipelining depths are reported, whatever `value` was measured at
+    assert abs(c["value_sync"] - d["value"]) < 1e-6 and c["value_pipelined"] > 0 and c["pipelined_frames_in_flight"] == 4
+    assert c["kernel_ms_cold"] > 0 and c["kernel_ms_orbit"] > 0 and c["stall_exits"] == 0
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf and "traffic_source" in rf
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None) or rf["valu_issue"] is not None
+    assert "k_render_tile" in rf["kernel"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
     assert d["value"] > 5 * cb["value"]
@@ -41,3 +47,4 @@ def test_bench_frames_in_flight_on_an_emulated_rank():
     c = d["config"]
     assert c["frames_in_flight"] == 4 and c["latency_ms_per_frame"] > 0 and "rank 1 of 2" in c["emulated_ranks"]
     assert d["value"] > 0 and d["kernel_ms"] > 0
+    assert abs(c["value_pipelined"] - d["value"]) < 1e-6 and c["value_sync"] > 0
