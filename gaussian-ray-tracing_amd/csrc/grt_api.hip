@@ -362,7 +362,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, &c->gbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, false, &c->gbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
@@ -438,23 +438,81 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
         rc = GRT_ERR_HIP;
     }
     if (rc == GRT_OK) {
+        (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, false, &c->mbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, false, true, &c->mbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK) {
         hipLaunchKernelGGL(k_gather_tris, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
                            c->mbvh.order, nf, c->d_tri);
+        (void)hipEventRecord(c->ev1, c->stream);
         e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) { c->err = std::string("grt_set_meshes: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+        else (void)hipEventElapsedTime(&c->mesh_update_ms, c->ev0, c->ev1);
     } else {
         (void)hipStreamSynchronize(c->stream); // host vectors are borrowed by the async copies
     }
     (void)hipFree(d_verts); (void)hipFree(d_lo); (void)hipFree(d_hi);
     if (rc != GRT_OK) { free_meshes(c); return rc; }
+    c->have_timing = false;
     c->n_faces = nf;
     c->n_verts = nv;
     return GRT_OK;
+}
+
+// Same meshes, moved (a gizmo drag: reference updateInstanceTransforms, src/GaussianTracer.cpp:711-736, rebuilds GAS and
+// IAS every time and leaks the old ones): new vertex positions / normals for the SAME topology; the mesh LBVH keeps its
+// hierarchy and only re-fits its boxes.  Fails with GRT_ERR_INVALID when the counts differ from the last grt_set_meshes.
+int grt_update_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
+{
+    if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
+    CHK(c, hipSetDevice(c->device));
+    uint64_t nv = 0, nf = 0;
+    for (uint32_t k = 0; k < n_meshes; k++) { nv += meshes[k].nv; nf += meshes[k].nf; }
+    if (nv != c->n_verts || nf != c->n_faces || nf == 0) {
+        c->err = "grt_update_meshes: vertex / face counts differ from the last grt_set_meshes (call that instead)";
+        return GRT_ERR_INVALID;
+    }
+    std::vector<float> v, nrm;
+    for (uint32_t k = 0; k < n_meshes; k++) {
+        const grt_mesh& m = meshes[k];
+        if (m.nv && (!m.verts || !m.normals)) { c->err = "grt_update_meshes: null array"; return GRT_ERR_INVALID; }
+        v.insert(v.end(), m.verts, m.verts + (size_t)m.nv * 3);
+        nrm.insert(nrm.end(), m.normals, m.normals + (size_t)m.nv * 3);
+    }
+    CHK(c, hipStreamSynchronize(c->stream));
+    float* d_verts = nullptr;
+    float4 *d_lo = nullptr, *d_hi = nullptr;
+    int rc = GRT_OK;
+    hipError_t e = hipSuccess;
+    if ((e = hipMalloc(&d_verts, (size_t)nv * 3 * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&d_lo, (size_t)nf * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(&d_hi, (size_t)nf * sizeof(float4))) != hipSuccess ||
+        (e = hipMemcpyAsync(d_verts, v.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(c->d_vnormals, nrm.data(), (size_t)nv * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream)) != hipSuccess) {
+        c->err = std::string("grt_update_meshes: ") + hipGetErrorString(e);
+        rc = GRT_ERR_HIP;
+    }
+    if (rc == GRT_OK) {
+        (void)hipEventRecord(c->ev0, c->stream);
+        hipLaunchKernelGGL(k_tri_boxes, dim3(((uint32_t)nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, (uint32_t)nf, d_lo, d_hi);
+        rc = refit_lbvh(d_lo, d_hi, (uint32_t)nf, &c->mbvh, c->stream, &c->err);
+    }
+    if (rc == GRT_OK) {
+        hipLaunchKernelGGL(k_gather_tris, dim3(((uint32_t)nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
+                           c->mbvh.order, (uint32_t)nf, c->d_tri);
+        (void)hipEventRecord(c->ev1, c->stream);
+        e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { c->err = std::string("grt_update_meshes: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+        else (void)hipEventElapsedTime(&c->mesh_update_ms, c->ev0, c->ev1);
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(d_verts); (void)hipFree(d_lo); (void)hipFree(d_hi);
+    c->have_timing = false;
+    return rc;
 }
 
 int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
@@ -468,6 +526,7 @@ int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
     o->mesh_faces = c->n_faces;
     o->mesh_height = c->mbvh.height;
     o->build_ms = c->build_ms;
+    o->mesh_update_ms = c->mesh_update_ms;
     for (int k = 0; k < 3; k++) { o->scene_lo[k] = c->gbvh.lo[k]; o->scene_hi[k] = c->gbvh.hi[k]; }
     return GRT_OK;
 }

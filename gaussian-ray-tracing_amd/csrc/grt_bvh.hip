@@ -439,14 +439,75 @@ void free_bvh(DevBvh* b)
 {
     if (b->qnodes) (void)hipFree(b->qnodes);
     if (b->pbox) (void)hipFree(b->pbox);
+    if (b->level) (void)hipFree(b->level);
     if (b->wnodes) (void)hipFree(b->wnodes);
     if (b->nodes) (void)hipFree(b->nodes);
     if (b->order) (void)hipFree(b->order);
     *b = DevBvh();
 }
 
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, DevBvh* out,
-               hipStream_t stream, std::string* err)
+// ---- refit: same hierarchy, new boxes ----
+__device__ __forceinline__ void refit_child_box(uint32_t c, const float4* __restrict__ nodes, const float4* __restrict__ lb_lo,
+                                                const float4* __restrict__ lb_hi, float lo[3], float hi[3])
+{
+    if (c & kLeafBit) { // leaf range: union of its primitives' boxes
+        const uint32_t first = leaf_first(c), cnt = leaf_count(c);
+        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (uint32_t j = 0; j < cnt; j++) {
+            const float4 l = lb_lo[first + j], h = lb_hi[first + j];
+            lo[0] = fminf(lo[0], l.x); lo[1] = fminf(lo[1], l.y); lo[2] = fminf(lo[2], l.z);
+            hi[0] = fmaxf(hi[0], h.x); hi[1] = fmaxf(hi[1], h.y); hi[2] = fmaxf(hi[2], h.z);
+        }
+        return;
+    }
+    const float4 q0 = nodes[(size_t)c * 4], q1 = nodes[(size_t)c * 4 + 1], q2 = nodes[(size_t)c * 4 + 2];
+    lo[0] = fminf(q0.x, q1.z); lo[1] = fminf(q0.y, q1.w); lo[2] = fminf(q0.z, q2.x);
+    hi[0] = fmaxf(q0.w, q2.y); hi[1] = fmaxf(q1.x, q2.z); hi[2] = fmaxf(q1.y, q2.w);
+}
+
+// nodes finished in build pass `pass` get their boxes again, from children finished in earlier passes (each launch is
+// one level, so every hand-off crosses a kernel boundary as in the build)
+__global__ void k_refit_level(float4* __restrict__ nodes, const uint32_t* __restrict__ level, int m, uint32_t pass,
+                              const float4* __restrict__ lb_lo, const float4* __restrict__ lb_hi)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1 || level[i] != pass) return;
+    const float4 q3 = nodes[(size_t)i * 4 + 3];
+    float l0[3], h0[3], l1[3], h1[3];
+    refit_child_box(__float_as_uint(q3.x), nodes, lb_lo, lb_hi, l0, h0);
+    refit_child_box(__float_as_uint(q3.y), nodes, lb_lo, lb_hi, l1, h1);
+    nodes[(size_t)i * 4 + 0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
+    nodes[(size_t)i * 4 + 1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
+    nodes[(size_t)i * 4 + 2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
+}
+
+int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err)
+{
+    float4 *d_lblo = nullptr, *d_lbhi = nullptr;
+    const uint32_t m = bvh->n_prims;
+    const int B = 256;
+    if (m == 0 || (bvh->root_ref & kLeafBit)) return GRT_OK; // no internal nodes: the leaves are tested directly
+    if (!bvh->level || !bvh->nodes || n_in < m) {
+        if (err) *err = "refit_lbvh: the BVH was not built with keep_levels";
+        return GRT_ERR_INVALID;
+    }
+    HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
+    HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((m + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, bvh->order, m, d_lblo, d_lbhi);
+    for (uint32_t pass = 1; pass <= bvh->height; pass++)
+        hipLaunchKernelGGL(k_refit_level, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, bvh->nodes, bvh->level, (int)m, pass,
+                           d_lblo, d_lbhi);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    (void)hipFree(d_lblo); (void)hipFree(d_lbhi);
+    return GRT_OK;
+fail:
+    (void)hipFree(d_lblo); (void)hipFree(d_lbhi);
+    return GRT_ERR_HIP;
+}
+
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
+               DevBvh* out, hipStream_t stream, std::string* err)
 {
     uint2* d_range = nullptr;
     uint32_t* d_bounds = nullptr;
@@ -505,7 +566,9 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     }
     if (out->qnodes) (void)hipFree(out->qnodes);
     if (out->pbox) (void)hipFree(out->pbox);
+    if (out->level) (void)hipFree(out->level);
     out->qnodes = out->pbox = nullptr;
+    out->level = nullptr;
     if (m) {
         HIPCHK(hipMalloc(&d_lblo, sizeof(float4) * m));
         HIPCHK(hipMalloc(&d_lbhi, sizeof(float4) * m));
@@ -569,6 +632,7 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         hipLaunchKernelGGL(k_qwiden, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->qnodes);
     }
     HIPCHK(hipStreamSynchronize(stream));
+    if (keep_levels) { out->level = d_level; d_level = nullptr; }
 done:
     HIPCHK(hipGetLastError());
     (void)hipFree(d_bounds); (void)hipFree(d_keys); (void)hipFree(d_keys2); (void)hipFree(d_vals);

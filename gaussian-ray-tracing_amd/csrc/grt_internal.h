@@ -40,6 +40,7 @@ struct DevBvh {
                                //   child c of node i at [i*2W + 2c] = (lo.xyz, ref bits), [+1] = (hi.xyz, 0); unused: ref kNoRoot
     float4* pbox = nullptr;    // [n_prims * 2] box of every sorted primitive, (lo.xyz,0)(hi.xyz,0): what a leaf-range
                                //   child expands to in the tile kernel (built only for the Gaussian BVH)
+    uint32_t* level = nullptr; // [n_prims-1] refit pass in which each node was finished (kept when asked for: refit_lbvh)
     uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
     uint32_t n_prims = 0;      // valid primitives (leaves)
     uint32_t height = 0;       // levels of internal nodes (bounds the traversal stack)
@@ -51,8 +52,12 @@ struct DevBvh {
 // Build an LBVH over n_in boxes (invalid primitives have lo.x > hi.x and are left out).
 // Returns GRT_OK or an error code (message in *err).
 // want_quad: also build the per-child layout (qnodes, pbox) the tile kernel traverses.
-int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, DevBvh* out,
-               hipStream_t stream, std::string* err);
+// keep_levels: keep the per-node refit order so that refit_lbvh can re-fit the boxes of the SAME hierarchy later.
+int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
+               DevBvh* out, hipStream_t stream, std::string* err);
+// Re-fit every reachable node's boxes to new primitive boxes (same primitives, same order, same hierarchy): what a
+// gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
+int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
 
 // Everything the render kernel reads, passed by value.
@@ -182,6 +187,7 @@ struct grt_ctx {
     size_t cap_rec = 0;
     bool built = false;
     float build_ms = 0.f;
+    float mesh_update_ms = 0.f; // device time of the last grt_set_meshes / grt_update_meshes
     // meshes
     grt::DevBvh mbvh;
     float4* d_tri = nullptr;

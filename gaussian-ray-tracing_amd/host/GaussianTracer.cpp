@@ -67,7 +67,7 @@ void GaussianTracer::initializeParams() // src/GaussianTracer.cpp:475-506
     stream = hipglue::streamCreate();
 }
 
-void GaussianTracer::render(HIPOutputBuffer& output_buffer) // src/GaussianTracer.cpp:508-538
+void GaussianTracer::render(CUDAOutputBuffer& output_buffer) // src/GaussianTracer.cpp:508-538
 {
     // (the reference pre-clears the frame in fisheye mode because its raygen leaves r > 1 pixels unwritten;
     //  the HIP kernel writes 0 there itself)
@@ -119,7 +119,7 @@ float3 GaussianTracer::primitivePosition() const // src/GaussianTracer.cpp:580-5
 // createGAS + createIAS + sendGeometryAttributesToDevice (src/GaussianTracer.cpp:592-600,653-709): every
 // primitive is placed in world space by its transform, normals by mat3(transform), and handed over whole;
 // the library rebuilds the mesh LBVH (no per-update leak, unlike :672-709,728).
-void GaussianTracer::uploadMeshes()
+void GaussianTracer::uploadMeshes(bool same_topology)
 {
     std::vector<Primitive>& ps = primitives->getPrimitives();
     std::vector<std::vector<float>> v(ps.size()), n(ps.size());
@@ -135,7 +135,9 @@ void GaussianTracer::uploadMeshes()
         }
         ms[k] = grt_mesh{v[k].data(), n[k].data(), (uint32_t)p.vertex_count, p.indices.data(), (uint32_t)(p.indices.size() / 3)};
     }
-    check(grt_set_meshes(m_ctx, ms.data(), (uint32_t)ms.size()), "grt_set_meshes");
+    // a moved primitive keeps its topology: re-fit the mesh LBVH; anything else (or a refused refit) rebuilds it
+    if (!same_topology || grt_update_meshes(m_ctx, ms.data(), (uint32_t)ms.size()) != GRT_OK)
+        check(grt_set_meshes(m_ctx, ms.data(), (uint32_t)ms.size()), "grt_set_meshes");
     params.mesh_handle = ps.empty() ? 0 : 1;
 }
 
@@ -147,7 +149,7 @@ void GaussianTracer::updateInstanceTransforms(Primitive& p) // src/GaussianTrace
 {
     std::vector<Primitive>& ps = primitives->getPrimitives();
     if (p.instanceIndex < ps.size() && &ps[p.instanceIndex] != &p) ps[p.instanceIndex].transform = p.transform;
-    uploadMeshes();
+    uploadMeshes(true);
 }
 
 void GaussianTracer::setSize(unsigned int width, unsigned int height) // src/GaussianTracer.cpp:796-800
@@ -163,19 +165,28 @@ float GaussianTracer::lastKernelMs()
     return ms;
 }
 
-// ---- HIPOutputBuffer ----
-HIPOutputBuffer::HIPOutputBuffer(unsigned int width, unsigned int height) { resize(width, height); }
-HIPOutputBuffer::~HIPOutputBuffer() { hipglue::deviceFree(m_device); }
-void HIPOutputBuffer::resize(unsigned int width, unsigned int height)
+// ---- HIPOutputBuffer (src/CUDAOutputBuffer.cpp:3-64) ----
+HIPOutputBuffer::HIPOutputBuffer(int32_t width, int32_t height) { resize(width, height); }
+HIPOutputBuffer::~HIPOutputBuffer()
 {
     hipglue::deviceFree(m_device);
-    m_device = nullptr;
-    m_width = width; m_height = height;
-    m_device = static_cast<uchar3*>(hipglue::deviceAlloc((size_t)width * height * 3));
-    m_host.assign((size_t)width * height * 3, 0);
+    hipglue::hostFreePinned(m_host);
 }
+void HIPOutputBuffer::resize(int32_t width, int32_t height)
+{
+    if (m_width == width && m_height == height && m_device) return;
+    hipglue::deviceFree(m_device);
+    hipglue::hostFreePinned(m_host);
+    m_device = nullptr; m_host = nullptr;
+    m_width = width; m_height = height;
+    const size_t bytes = (size_t)width * height * 3;
+    m_device = static_cast<uchar3*>(hipglue::deviceAlloc(bytes));
+    m_host = static_cast<uchar3*>(hipglue::hostAllocPinned(bytes));
+}
+void HIPOutputBuffer::unmap() { hipglue::copyToHostAsync(m_host, m_device, (size_t)m_width * m_height * 3, m_stream); }
 const std::vector<unsigned char>& HIPOutputBuffer::download()
 {
-    hipglue::copyToHost(m_host.data(), m_device, m_host.size());
-    return m_host;
+    m_copy.resize((size_t)m_width * m_height * 3);
+    hipglue::copyToHost(m_copy.data(), m_device, m_copy.size());
+    return m_copy;
 }

@@ -23,7 +23,7 @@ public:
     void initializeOptix();                 // name kept for drop-in; builds the HIP scene + LBVH
     void initialize() { initializeOptix(); }
 
-    void render(HIPOutputBuffer& output_buffer);
+    void render(CUDAOutputBuffer& output_buffer); // CUDAOutputBuffer = HIPOutputBuffer (HIPOutputBuffer.h)
 
     void updateCamera(Camera& camera, bool& camera_changed);
     void updateInstanceTransforms(Primitive& p);
@@ -50,7 +50,7 @@ public:
 private:
     void initializeParams();
     void createGaussianParticlesBVH();
-    void uploadMeshes();
+    void uploadMeshes(bool same_topology = false);
     float3 primitivePosition() const;
     void check(int rc, const char* what);
 

@@ -16,4 +16,7 @@ void streamSync(void* s) { chk(hipStreamSynchronize((hipStream_t)s), "hipStreamS
 void* deviceAlloc(size_t bytes) { void* p = nullptr; chk(hipMalloc(&p, bytes), "hipMalloc"); return p; }
 void deviceFree(void* p) { if (p) (void)hipFree(p); }
 void copyToHost(void* dst, const void* src, size_t bytes) { chk(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "hipMemcpy"); }
+void* hostAllocPinned(size_t bytes) { void* p = nullptr; chk(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc"); return p; }
+void hostFreePinned(void* p) { if (p) (void)hipHostFree(p); }
+void copyToHostAsync(void* dst, const void* src, size_t bytes, void* stream) { chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync"); }
 }

@@ -9,4 +9,7 @@ void  streamSync(void* stream);
 void* deviceAlloc(size_t bytes);
 void  deviceFree(void* p);
 void  copyToHost(void* dst, const void* src, size_t bytes);
+void* hostAllocPinned(size_t bytes);
+void  hostFreePinned(void* p);
+void  copyToHostAsync(void* dst, const void* src, size_t bytes, void* stream);
 }

@@ -36,7 +36,7 @@ class Counters(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_particles", C.c_uint64), ("n_proxies", C.c_uint64), ("n_nodes", C.c_uint32),
                 ("height", C.c_uint32), ("mesh_faces", C.c_uint32), ("mesh_height", C.c_uint32),
-                ("build_ms", C.c_float), ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3)]
+                ("build_ms", C.c_float), ("mesh_update_ms", C.c_float), ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3)]
 
 
 class Gaussians(C.Structure):
@@ -55,7 +55,7 @@ KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERN
 
 EXPORTS = [
     "grt_create", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
-    "grt_set_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_render_rays", "grt_sync",
+    "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_render_rays", "grt_sync",
     "grt_get_counters", "grt_last_kernel_ms", "grt_host_activate", "grt_host_uvw_frame", "grt_host_synth_scene",
     "grt_host_ply_count", "grt_host_ply_read", "grt_host_ply_write", "grt_host_last_error",
     "grt_host_primitive_counts", "grt_host_primitive_fill", "grt_host_obj_count", "grt_host_obj_read", "grt_host_obj_write",
@@ -89,6 +89,7 @@ def lib():
         L.grt_upload_gaussians.argtypes = [vp, C.POINTER(Gaussians), u64]
         L.grt_build_bvh.argtypes = [vp, fl]
         L.grt_set_meshes.argtypes = [vp, C.POINTER(Mesh), u32]
+        L.grt_update_meshes.argtypes = [vp, C.POINTER(Mesh), u32]
         L.grt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
         L.grt_render.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, vp]
         L.grt_render_tiles.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, u32, vp]
@@ -298,6 +299,16 @@ class Tracer:
             keep += [v, n, f]
             arr[i] = Mesh(v.ctypes.data, n.ctypes.data, len(v), f.ctypes.data, len(f))
         self._check(lib().grt_set_meshes(self._h, arr, len(meshes)))
+
+    def update_meshes(self, meshes):
+        """Same topology, new positions / normals: the mesh LBVH is re-fitted, not rebuilt."""
+        keep, arr = [], (Mesh * max(len(meshes), 1))()
+        for i, (v, n, f) in enumerate(meshes):
+            v = np.ascontiguousarray(v, np.float32); n = np.ascontiguousarray(n, np.float32)
+            f = np.ascontiguousarray(f, np.uint32)
+            keep += [v, n, f]
+            arr[i] = Mesh(v.ctypes.data, n.ctypes.data, len(v), f.ctypes.data, len(f))
+        self._check(lib().grt_update_meshes(self._h, arr, len(meshes)))
 
     def bvh_info(self):
         o = BvhInfo()

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "../host/Display.h"
 #include "../host/GaussianTracer.h"
 
 // Minimal PNG writer (8-bit RGB, stored deflate blocks: no compression library needed; CRC-32 and Adler-32 per the
@@ -75,12 +76,15 @@ static void usage()
 {
     std::puts("usage: grt_render [-p|--ply scene.ply] [--width W] [--height H] [--fisheye] [--type mirror|normal|glass]\n"
               "                  [--sh-degree 0..3] [--plane] [--sphere] [--obj mesh.obj] [--bounces N]\n"
-              "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png] [--bench N]");
+              "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png] [--raw frame.rgb]\n"
+              "                  [--move dx dy dz] [--bench N]");
 }
 
 int main(int argc, char** argv)
 {
-    std::string ply = "../data/train.ply", out, obj;
+    std::string ply = "../data/train.ply", out, obj, raw_out;
+    float move[3] = {0.0f, 0.0f, 0.0f};
+    bool have_move = false;
     unsigned int width = 1280, height = 720, sh_degree = 0, bounces = 32;
     bool fisheye = false, plane = false, sphere = false;
     int type = MIRROR, bench = 0;
@@ -101,6 +105,8 @@ int main(int argc, char** argv)
         else if (a == "--fov") { need(1); fov = (float)std::atof(argv[++i]); }
         else if (a == "--eye") { need(3); for (int k = 0; k < 3; k++) eye[k] = (float)std::atof(argv[++i]); }
         else if (a == "--out") { need(1); out = argv[++i]; }
+        else if (a == "--raw") { need(1); raw_out = argv[++i]; }
+        else if (a == "--move") { need(3); for (int k = 0; k < 3; k++) move[k] = (float)std::atof(argv[++i]); have_move = true; }
         else if (a == "--bench") { need(1); bench = std::atoi(argv[++i]); }
         else if (a == "--type") {
             need(1);
@@ -128,8 +134,13 @@ int main(int argc, char** argv)
         if (plane) tracer.createPlane();        // gui.cpp:170
         if (sphere) tracer.createSphere();      // gui.cpp:173
         if (!obj.empty()) tracer.createLoadMesh(obj);
+        if (have_move && !tracer.getPrimitives().empty()) { // a gizmo drag of the last primitive (src/gui.cpp:430-433)
+            Primitive& pr = tracer.getPrimitives().back();
+            pr.transform.m[3][0] += move[0]; pr.transform.m[3][1] += move[1]; pr.transform.m[3][2] += move[2];
+            tracer.updateInstanceTransforms(pr);
+        }
 
-        HIPOutputBuffer output_buffer(width, height);
+        CUDAOutputBuffer output_buffer(width, height); // = HIPOutputBuffer (src/main.cpp:77)
         output_buffer.setStream(tracer.stream);
         tracer.render(output_buffer);
         if (bench > 0) {
@@ -147,11 +158,13 @@ int main(int argc, char** argv)
             std::printf("frames %d  median %.3f ms/frame  kernel %.3f ms  %.1f Mrays/s (primary)\n", bench, med, kms / bench,
                         (double)width * height / med / 1e3);
         }
+        if (!raw_out.empty()) { // the buffer as the renderer wrote it (row 0 first), from the pinned mirror render() filled
+            std::ofstream f(raw_out, std::ios::binary);
+            f.write(reinterpret_cast<const char*>(output_buffer.getHostPointer()), (std::streamsize)((size_t)width * height * 3));
+        }
         if (!out.empty()) {
-            const std::vector<unsigned char>& rgb = output_buffer.download();
-            std::vector<unsigned char> top_down((size_t)width * height * 3);
-            for (unsigned int y = 0; y < height; y++) // row 0 is the bottom of the window (src/Display.cpp:13,184)
-                memcpy(top_down.data() + (size_t)y * width * 3, rgb.data() + (size_t)(height - 1 - y) * width * 3, (size_t)width * 3);
+            // what the viewer's window shows: buffer row 0 at the bottom (src/Display.cpp:13,184)
+            const std::vector<unsigned char> top_down = GLDisplay::windowImage(output_buffer);
             if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
                 write_png(out, top_down.data(), width, height);
             } else {

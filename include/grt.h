@@ -15,6 +15,7 @@
  *                                 buildAccelationStructure (OptiX, closed)   319-399, 422-473
  *   grt_set_meshes                createGAS+createIAS for primitives,      src/GaussianTracer.cpp:578-709
  *                                 sendGeometryAttributesToDevice
+ *   grt_update_meshes             updateInstanceTransforms (refit, no rebuild) src/GaussianTracer.cpp:711-794
  *   grt_render                    render(): param upload + optixLaunch of  src/GaussianTracer.cpp:508-538,
  *                                 raygen/anyhit/closesthit/miss              shaders/tracer.cu:17-187
  *   grt_render_tiles              (new) screen-tile sharding for N GPUs    SURVEY.md §8(e)
@@ -111,6 +112,7 @@ typedef struct {
     uint32_t mesh_faces;
     uint32_t mesh_height;
     float build_ms;         /* device time of the last grt_build_bvh */
+    float mesh_update_ms;   /* device time of the last grt_set_meshes (build) / grt_update_meshes (refit) */
     float scene_lo[3], scene_hi[3];
 } grt_bvh_info;
 
@@ -150,6 +152,10 @@ GRT_API int grt_set_option(grt_ctx* ctx, int option, int value);
 GRT_API int grt_upload_gaussians(grt_ctx* ctx, const grt_gaussians* host, uint64_t n);
 GRT_API int grt_build_bvh(grt_ctx* ctx, float alpha_min);
 GRT_API int grt_set_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_meshes);
+/* The same meshes, moved: new positions / normals for the topology of the last grt_set_meshes (same nv, nf per
+ * mesh).  The mesh LBVH keeps its hierarchy and re-fits its boxes (reference: updateInstanceTransforms rebuilds GAS +
+ * IAS on every gizmo frame and leaks the old ones, src/GaussianTracer.cpp:711-794).  GRT_ERR_INVALID when counts differ. */
+GRT_API int grt_update_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_meshes);
 GRT_API int grt_get_bvh_info(const grt_ctx* ctx, grt_bvh_info* out);
 
 /* ---- render (all asynchronous on `stream`, a hipStream_t; NULL = the context's own stream) ----

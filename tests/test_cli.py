@@ -119,3 +119,35 @@ def test_cli_mirror_mesh_matches_oracle(tmp_path, kind):
     bad = (np.abs(got.astype(int) - ref.astype(int)) > 1).any(-1).mean()
     assert bad <= tol_frac, bad
     assert cnt["segments"] > cnt["rays"]
+
+
+@pytest.mark.gpu
+def test_cli_viewer_glue_row_zero_is_the_bottom_and_drag_refits(tmp_path):
+    """Viewer glue: render(CUDAOutputBuffer&) fills the pinned host mirror, whose row 0 is the
+    renderer's row 0 and the BOTTOM row of the window image (src/Display.cpp:13,184); a gizmo drag through
+    updateInstanceTransforms (mesh LBVH re-fit) gives the oracle's frame of the moved sphere."""
+    ply, acts = _scene(tmp_path)
+    W, H = 144, 80
+    center = grt.gaussian_center(acts["pos"])
+    pos = (center * np.float32(0.25) + np.float32([0, 0, 3]) * np.float32(0.75)).astype(np.float32)
+    move = np.float32([0.2, 0.15, -0.1])
+    out, raw = str(tmp_path / "f.ppm"), str(tmp_path / "f.rgb")
+    r = subprocess.run([CLI, "-p", ply, "--width", str(W), "--height", str(H), "--out", out, "--raw", raw, "--type", "mirror",
+                        "--bounces", "3", "--sphere", "--move", *(repr(float(x)) for x in move)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    buf = np.fromfile(raw, np.uint8).reshape(H, W, 3)       # the pinned mirror, row 0 first
+    with open(out, "rb") as f:                                # the window image, top row first
+        assert f.readline().strip() == b"P6"; f.readline(); f.readline()
+        img = np.frombuffer(f.read(), np.uint8).reshape(H, W, 3)
+    assert (img[H - 1] == buf[0]).all() and (img[0] == buf[H - 1]).all() and (img[::-1] == buf).all()
+    v, n, fcs = grt.primitive_mesh(grt.PRIM_SPHERE)
+    vv = ((v + pos[None]).astype(np.float32) + move[None]).astype(np.float32)  # translate(position) then the drag
+    p = grt.default_params(W, H, center, mesh_type=grt.MIRROR, max_bounces=3)
+    sc = O.Scene(acts_to_particles(acts))
+    sc.set_mesh(vv, n, fcs)
+    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    assert cnt["segments"] > cnt["rays"]
+    bad = (np.abs(buf.astype(int) - ref.astype(int)) > 1).any(-1).mean()
+    assert bad <= 2e-3, bad  # float association of (v + pos) + move may differ by an ulp from the facade's matrix product
+    top, bottom = buf[H - 8:].astype(int).sum(), buf[:8].astype(int).sum()
+    assert top != bottom  # the frame is not symmetric: the orientation check above has teeth

@@ -384,3 +384,39 @@ def test_option_values_are_validated():
             t.upload(grt.activate(raw), alpha_min=0.0)
     finally:
         t.close()
+
+
+def test_moved_mesh_refit_matches_rebuild_and_oracle(tr):
+    """grt_update_meshes (a gizmo drag: reference updateInstanceTransforms, src/GaussianTracer.cpp:711-736): the mesh LBVH
+    keeps its hierarchy and re-fits its boxes.  A moved / rotated sphere must render exactly as a freshly built one,
+    and as the oracle's."""
+    acts, p, sc, op, center = make_scene(41, 5000, 160, 120, scale_boost=0.5, mesh_type=grt.MIRROR, max_bounces=3)
+    pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+    v0, n0, f = grt.sphere_mesh((0, 0, 0), tess_u=48, tess_v=24)
+    tr.upload(acts)
+    tr.set_meshes([(v0 + pos, n0, f)])
+    a8, af = tr.render(p, want_f32=True)
+    a8, af = a8.clone(), af.clone()
+    build_ms = tr.bvh_info()["mesh_update_ms"]
+    # drag: rotate about z by 40 degrees, scale 1.3 in x, translate (positions by M, normals by mat3(M): GaussianTracer.cpp:659-662)
+    ang = np.float32(np.deg2rad(40.0)); c_, s_ = np.cos(ang), np.sin(ang)
+    M = (np.float32([[c_, -s_, 0], [s_, c_, 0], [0, 0, 1]]) @ np.diag(np.float32([1.3, 1.0, 1.0]))).astype(np.float32)
+    v1 = (v0 @ M.T + pos + np.float32([0.25, -0.1, -0.2])).astype(np.float32)
+    n1 = (n0 @ M.T).astype(np.float32)
+    tr.update_meshes([(v1, n1, f)])
+    refit_ms = tr.bvh_info()["mesh_update_ms"]
+    b8, bf = tr.render(p, want_f32=True)
+    b8, bf = b8.clone(), bf.clone()
+    assert not (b8 == a8).all()
+    tr.set_meshes([(v1, n1, f)])  # fresh build of the moved mesh
+    c8, cf = tr.render(p, want_f32=True)
+    assert (c8 == b8).all() and (cf == bf).all()
+    sc.set_mesh(v1, n1, f)
+    ref_u8, ref_f32, rc = sc.render(op)
+    compare(bf, ref_f32, b8, ref_u8)
+    assert rc["segments"] > rc["rays"] and refit_ms > 0 and build_ms > 0
+    # a different topology is refused (the facade then rebuilds)
+    v2, n2, f2 = grt.sphere_mesh(pos, tess_u=16, tess_v=8)
+    with pytest.raises(grt.GrtError, match="counts differ"):
+        tr.update_meshes([(v2, n2, f2)])
+    tr.set_meshes([])
