@@ -287,6 +287,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_TILE_READY_MIN) { c->opt_tile_ready = std::min(64, std::max(1, value)); }
     else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
     else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
+    else if (option == GRT_OPT_SIZE_CLASSES) { g_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }

@@ -26,6 +26,8 @@
 
 namespace grt {
 
+int g_size_classes = 1; // Gaussian BVH: size classes in the Morton key (GRT_OPT_SIZE_CLASSES; testing knob)
+
 #define HIPCHK(x)                                                                                     \
     do {                                                                                              \
         hipError_t e_ = (x);                                                                          \
@@ -52,11 +54,12 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o)
 #endif
 }
 
-// bounds[0..2] = min centroid (ordered uint), [3..5] = max, [6] = valid count
+// bounds[0..2] = min centroid (ordered uint), [3..5] = max, [6] = valid count, [7] = sum of the box diagonals (float)
 __global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
                                uint32_t* __restrict__ bounds)
 {
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0}, cnt = 0;
+    float dsum = 0.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 l = lo[i], h = hi[i];
         if (l.x <= h.x) {
@@ -67,6 +70,7 @@ __global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __re
                 mx[k] = max(mx[k], o);
             }
             cnt++;
+            dsum += sqrtf((h.x - l.x) * (h.x - l.x) + (h.y - l.y) * (h.y - l.y) + (h.z - l.z) * (h.z - l.z));
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -75,13 +79,28 @@ __global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __re
             mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], off));
         }
         cnt += (uint32_t)__shfl_xor((int)cnt, off);
+        dsum += __shfl_xor(dsum, off);
     }
+    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<float*>(&bounds[7]), dsum);
+    // one set of atomics per WORKGROUP (the waves meet in LDS first): 7 x 256 atomics instead of 7 x 8192 on one line
+    __shared__ uint32_t red[4][7];
+    const uint32_t wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 3; k++) {
-            atomicMin(&bounds[k], mn[k]);
-            atomicMax(&bounds[3 + k], mx[k]);
+        for (int k = 0; k < 3; k++) { red[wv][k] = mn[k]; red[wv][3 + k] = mx[k]; }
+        red[wv][6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nw = (blockDim.x + 63u) >> 6;
+        for (uint32_t w = 1; w < nw; w++) {
+            for (int k = 0; k < 3; k++) { red[0][k] = min(red[0][k], red[w][k]); red[0][3 + k] = max(red[0][3 + k], red[w][3 + k]); }
+            red[0][6] += red[w][6];
         }
-        atomicAdd(&bounds[6], cnt);
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&bounds[k], red[0][k]);
+            atomicMax(&bounds[3 + k], red[0][3 + k]);
+        }
+        atomicAdd(&bounds[6], red[0][6]);
     }
 }
 
@@ -98,7 +117,7 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v)
 
 __global__ void k_morton(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
                          const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys,
-                         uint32_t* __restrict__ vals)
+                         uint32_t* __restrict__ vals, int size_classes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -115,6 +134,16 @@ __global__ void k_morton(const float4* __restrict__ lo, const float4* __restrict
             q[k] = min((uint32_t)(u * 2097152.0f), 2097151u);
         }
         key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+        // Size classes.  A primitive much larger than the average (a needle / pancake Gaussian, a background splat) sits
+        // among small neighbours in Morton order and inflates every ancestor's box.  The two key bits ABOVE the 61-bit
+        // code (the code gives up its two lowest bits) hold log_6 of its diagonal over the mean diagonal, clamped to
+        // 0..3: Karras splits on those bits first, so each class gets a subtree of its own under the root and the
+        // normal-sized majority keeps tight boxes (LBVH-quality measure of SURVEY §7.5; a pure re-ordering of the
+        // primitives: hits never depend on it).
+        const float mean_d = __uint_as_float(bounds[7]) / fmaxf((float)bounds[6], 1.0f);
+        const float d = sqrtf((h.x - l.x) * (h.x - l.x) + (h.y - l.y) * (h.y - l.y) + (h.z - l.z) * (h.z - l.z));
+        const uint32_t cls = size_classes ? ((d > 216.0f * mean_d) ? 3u : (d > 36.0f * mean_d) ? 2u : (d > 6.0f * mean_d) ? 1u : 0u) : 0u;
+        key = (key >> 2) | ((uint64_t)cls << 61);
     }
     keys[i] = key;
     vals[i] = i;
@@ -516,7 +545,7 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     float4 *d_lblo = nullptr, *d_lbhi = nullptr;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
-    uint32_t h_bounds[7];
+    uint32_t h_bounds[8];
     uint32_t m = 0;
     const int B = 256;
 
@@ -530,9 +559,9 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         return GRT_ERR_LIMIT;
     }
 
-    HIPCHK(hipMalloc(&d_bounds, 7 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_bounds, 8 * sizeof(uint32_t)));
     {
-        const uint32_t init[7] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0};
+        const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
     }
     HIPCHK(hipMalloc(&d_keys, sizeof(uint64_t) * n_in));
@@ -546,10 +575,10 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         out->cap_order = n_in;
     }
     {
-        const int grid = (int)std::min<uint32_t>((n_in + B - 1) / B, 2048u);
+        const int grid = (int)std::min<uint32_t>((n_in + B - 1) / B, 256u);
         hipLaunchKernelGGL(k_scene_bounds, dim3(grid), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds);
         hipLaunchKernelGGL(k_morton, dim3((n_in + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds, d_keys,
-                           d_vals);
+                           d_vals, want_quad ? g_size_classes : 0);
     }
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
                                      stream));

@@ -59,6 +59,7 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
 // gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
 int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
+extern int g_size_classes;
 
 // Everything the render kernel reads, passed by value.
 struct RenderArgs {

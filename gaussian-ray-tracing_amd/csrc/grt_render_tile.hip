@@ -63,6 +63,12 @@ constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's 
 // Diagnostic build (make EXTRA=-DGRT_TILE_DIAG, never shipped; counters on): the counters hold WAVE-level trip counts —
 // rays: node steps, segments: particles fetched, hit_evals: compositing steps, rounds: passes, node_visits: depth-first
 // pops, proxy_tests: exact tests executed, rec_fetches: leaf steps, stall_exits: frontier rebalances.
+// Checking build (make EXTRA=-DGRT_TILE_CHECK, never shipped): stall_exits counts violated invariants (an event turning
+// up below the front: +1 per lane; frontier entries not conserved by a rebalance: +1000 per lane) and, when a float
+// frame is rendered, row 0 of it receives the (t, 2 id + exit, T) log of the events lane GRT_TILE_CHECK_LANE composites.
+#ifndef GRT_TILE_CHECK_LANE
+#define GRT_TILE_CHECK_LANE 0u
+#endif
 #ifdef GRT_TILE_DIAG
 #define GRT_D(f, n) if (COUNT) w.f += (n);
 #elif defined(GRT_MARKS)
@@ -233,6 +239,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         uint32_t pmask = 0; // payload cells in use
         uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
         bool watchdog = false;
+#ifdef GRT_TILE_CHECK
+        uint32_t dbg_n = 0, dbg_m = 0;
+#endif
         uint32_t chunk = kNoRoot; // this tile's chunk of the overflow pool (taken at the first window overflow)
         const uint32_t ready_min = a.tile_ready_min; // lanes with a final event before a compositing sweep starts
 
@@ -282,7 +291,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     float Ff = wave_min(fl);
                     if (nbag) {
                         const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
-                        if (rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * a.tile_look) && (nocc_ + 8u <= kKeep))) {
+                        // (everything but one entry may end up in the bag: only when frontier + bag fit it)
+                        if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * a.tile_look) && (nocc_ + 8u <= kKeep))) &&
+                            (nocc_ + nbag <= kBag)) {
                             // ---- rebalance: the nearest kKeep entries of (frontier + bag) stay in registers, the rest
                             //      goes (back) to the bag.  Everything passes through registers: 4 bag entries per lane.
                             GRT_D(stall_exits, 1)
@@ -344,6 +355,20 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                                 fr = v_.y;
                             }
                             wave_fence();
+#ifdef GRT_TILE_CHECK
+                            if (nk + nfar != nocc_ + nbag) {
+                                c.stall_exits += 1000u; // conservation of the frontier entries
+                                if (a.outf && lane == 0u) {
+                                    float* q_ = a.outf + (size_t)a.p.width * 3 + dbg_m * 12; // row 1 of the frame
+                                    q_[0] = (float)nk; q_[1] = (float)nfar; q_[2] = (float)nocc_; q_[3] = (float)nbag; q_[4] = th; q_[5] = lo0;
+                                    q_[6] = (float)__popcll(wave_ballot(br0 != kNoRoot)); q_[7] = (float)__popcll(wave_ballot(br1 != kNoRoot));
+                                    q_[8] = (float)__popcll(wave_ballot(br2 != kNoRoot)); q_[9] = (float)__popcll(wave_ballot(br3 != kNoRoot));
+                                    q_[10] = (float)iters;
+                                }
+                                dbg_m++;
+                            }
+                            if ((uint32_t)__popcll(wave_ballot(fr != kNoRoot)) != nk) c.stall_exits += 100000u;
+#endif
                             nbag = nfar;
                             Fbag = nfar ? wave_min(far_min) : INFINITY;
                             rebal = false;
@@ -438,6 +463,12 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                             if (!SH) cc = a.color0[id];
                         }
                         SLOT_SHIFT_ALL(cm_)
+#ifdef GRT_TILE_CHECK
+                        if (can_ && a.outf && lane == GRT_TILE_CHECK_LANE && dbg_n < 1900u) { // event log of one lane
+                            a.outf[dbg_n * 3] = key_t(ek); a.outf[dbg_n * 3 + 1] = (float)(id * 2u + ((((uint32_t)ek) >> 5) & 1u)); a.outf[dbg_n * 3 + 2] = T;
+                            dbg_n++;
+                        }
+#endif
                         if (can_) { // shaders/tracer.cuh:352-367
                             if (COUNT) c.hit_evals++;
                             last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
@@ -614,6 +645,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                         const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
                         const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
                         const bool ins = (k_first != kKeyInvalid) && (k_first < lost);
+#ifdef GRT_TILE_CHECK
+                        if (ins && key_t(k_first) < F) c.stall_exits++; // finality violated: an event below the front turned up late
+#endif
                         if (wave_any(ins)) { // wave-uniform branch
                             // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
                             const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
@@ -660,7 +694,8 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     const uint64_t fm = wave_ballot(fr == kNoRoot);
                     const uint32_t nc = (uint32_t)__popcll(wm), nf = (uint32_t)__popcll(fm);
                     const uint32_t crk = lanes_below(wm), frk = lanes_below(fm);
-                    if (nc > nf && !dfs && nbag + nc <= kBag) {
+                    // (a rebalance may send every entry but one to the bag: frontier + bag + these must fit it)
+                    if (nc > nf && !dfs && nbag + nc + 64u <= kBag) {
                         // no room: park all of them in the bag; the next iteration keeps the nearest entries of
                         // (frontier + bag) in registers
                         if (want) bag[nbag + crk] = make_uint2(__float_as_uint(lam), cref);

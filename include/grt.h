@@ -140,7 +140,9 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */,
        GRT_OPT_TILE_PRIO_DIV = 12     /* the heaviest 1/value of the tiles (by last frame's cost) run at raised wave priority; 0 = off */,
        GRT_OPT_COST_RADIUS = 13       /* scheduling feedback under a moving camera: a tile's cost is the largest of last frame's costs
-                                         within value tiles of it (default 4; 0 = the tile's own cost) */ };
+                                         within value tiles of it (default 4; 0 = the tile's own cost) */,
+       GRT_OPT_SIZE_CLASSES = 14      /* 1 (default): proxies much larger than average get subtrees of their own in the Gaussian LBVH
+                                         (size class in the top Morton bits); 0: plain Morton order.  Process-wide; next build */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
