@@ -411,14 +411,17 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                             //      than the window's last key goes in (sorted insert) and the displaced last key takes
                             //      its place in the bag (compacted in place: position w <= i) ----
                             GRT_D(node_visits, 1)
-                            uint32_t nmax = need ? nb : 0u;
+                            // lanes that do not need it yet but have room for four more keys come along: one scan instead
+                            // of one per lane a few steps apart
+                            const bool rf = need || (alive && (nb != 0u) && (k8 == kKeyInvalid) && (bagmin < lost));
+                            uint32_t nmax = rf ? nb : 0u;
                             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
                             nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
                             uint32_t w_ = 0;
                             uint64_t newmin = kKeyInvalid;
                             float4* bp = a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane;
                             for (uint32_t i = 0; i < nmax; i++) {
-                                const bool v_ = need && (i < nb);
+                                const bool v_ = rf && (i < nb);
                                 float4 e_ = make_float4(0.f, 0.f, 0.f, 0.f);
                                 if (v_) e_ = bp[(size_t)i * 64u];
                                 const uint64_t ekey = ((uint64_t)__float_as_uint(e_.y) << 32) | (uint64_t)__float_as_uint(e_.x);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                                     w_++;
                                 }
                             }
-                            if (need) {
+                            if (rf) {
                                 nb = w_;
                                 bagmin = newmin;
                             }
