@@ -237,13 +237,24 @@ def main():
     one_frame()
     cnt = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
-    cold_ms = orbit_ms = None
+    cold_ms = cold_wall_ms = cold_screen_ms = orbit_ms = None
     if extra:
-        # a frame without scheduling feedback (what a cold start / a camera cut costs), for the record
-        tr.set_option(grt.OPT_FEEDBACK, 0)
+        # a COLD frame: no costs of a previous frame (first frame, camera cut, new size).  The tiles are then ordered by a
+        # projected particle count (one extra pass over the particle positions, inside the wall time below, outside
+        # the kernel bracket); for the record also in plain screen order (GRT_OPT_COLD_ESTIMATE = 0)
+        def cold_frame():
+            tr.set_option(grt.OPT_FEEDBACK, 1)  # forgets the cost map
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            one_frame()
+            torch.cuda.synchronize()
+            return tr.last_kernel_ms(), (time.perf_counter() - tc) * 1e3
+        cold = [cold_frame() for _ in range(3)]
+        cold_ms, cold_wall_ms = float(np.median([x[0] for x in cold])), float(np.median([x[1] for x in cold]))
+        tr.set_option(grt.OPT_COLD_ESTIMATE, 0)
+        cold_screen_ms = float(np.median([cold_frame()[0] for _ in range(3)]))
+        tr.set_option(grt.OPT_COLD_ESTIMATE, 1)
         one_frame(); one_frame()
-        cold_ms = tr.last_kernel_ms()
-        tr.set_option(grt.OPT_FEEDBACK, 1)
         # a MOVING camera: the eye orbits the look-at point by 1.5 degrees per frame (the per-eye records are rebuilt
         # and the previous frame's tile costs order a slightly different frame); median over the last 8 of 10 frames
         mm = []
@@ -373,10 +384,13 @@ def main():
                        "bvh_height": info["height"], "n_proxies": info["n_proxies"], "bvh_build_ms": round(info["build_ms"], 2),
                        "setup_s": round(setup_s, 2), "kernel_variant": args.kernel,
                        "scheduling": "8x8 tiles launched heaviest-first from the previous frame's per-tile cost "
-                                     "(steady state of an interactive viewer); kernel_ms_cold is one frame without it; "
+                                     "(steady state of an interactive viewer); kernel_ms_cold / frame_ms_cold (wall, synchronised): a frame with no "
+                                     "previous costs, tiles ordered by projected particle counts; kernel_ms_cold_screen_order: the same in screen order; "
                                      "kernel_ms_orbit: the eye orbits the look-at point by 1.5 degrees per frame "
                                      "(per-eye records rebuilt, last frame's costs order a different frame)",
                        "kernel_ms_cold": None if cold_ms is None else round(cold_ms, 4),
+                       "frame_ms_cold": None if cold_wall_ms is None else round(cold_wall_ms, 4),
+                       "kernel_ms_cold_screen_order": None if cold_screen_ms is None else round(cold_screen_ms, 4),
                        "kernel_ms_orbit": None if orbit_ms is None else round(orbit_ms, 4)},
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

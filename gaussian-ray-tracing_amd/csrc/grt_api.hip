@@ -183,6 +183,52 @@ __global__ void k_gather_tris(const float* __restrict__ verts, const uint32_t* _
     tri[(size_t)j * 3 + 2] = make_float4(verts[i2 * 3], verts[i2 * 3 + 1], verts[i2 * 3 + 2], 0.0f);
 }
 
+// Cold-start scheduling estimate: how many particle centres project into each 8x8 tile (scheduling unit).  Used ONLY to
+// order the launch of a frame that has no previous-frame costs (first frame, camera cut, new size): dense tiles first.
+// The projection inverts getRay / getFishEyeRay (shaders/tracer.cuh:115-165) for a point instead of a pixel; it never
+// touches a pixel value.
+__global__ void k_estimate_costs(const float* __restrict__ pos, uint32_t n, uint32_t stride, const RenderArgs a,
+                                 uint32_t* __restrict__ cost)
+{
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * stride; // a sample of the particles is enough for an ORDER
+    if (i >= n) return;
+    const f3 v = sub3(mk3(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]), mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]));
+    const f3 U = mk3(a.p.U[0], a.p.U[1], a.p.U[2]), V = mk3(a.p.V[0], a.p.V[1], a.p.V[2]), W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
+    // components of v in the (-U, -V, W) basis the ray generators use (the three are mutually orthogonal)
+    const float su = -dot3(v, U) / fmaxf(dot3(U, U), 1e-30f), sv = -dot3(v, V) / fmaxf(dot3(V, V), 1e-30f),
+                sw = dot3(v, W) / fmaxf(dot3(W, W), 1e-30f);
+    float dx, dy;
+    if (!a.p.mode_fisheye) {
+        if (!(sw > 1e-6f)) return; // behind the camera
+        dx = su / sw; dy = sv / sw;
+    } else {
+        const float len = sqrtf(su * su + sv * sv + sw * sw);
+        if (!(len > 0.0f)) return;
+        const float ct = fminf(fmaxf(sw / len, -1.0f), 1.0f);
+        const float r = sqrtf(2.0f) * sqrtf(fmaxf(0.5f * (1.0f - ct), 0.0f)); // sqrt(2) sin(theta / 2)
+        const float rho = sqrtf(su * su + sv * sv);
+        if (!(r <= 1.0f) || !(rho > 0.0f)) return;
+        dx = r * su / rho; dy = r * sv / rho;
+    }
+    const float fx = (dx + 1.0f) * 0.5f * (float)a.p.width, fy = (dy + 1.0f) * 0.5f * (float)a.p.height;
+    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)a.p.width && fy < (float)a.p.height)) return;
+    const uint32_t px = (uint32_t)fx, py = (uint32_t)fy;
+    uint32_t blk, lx, ly;
+    if (a.mode == 0) {
+        if (px < a.x0 || py < a.y0 || px >= a.x1 || py >= a.y1) return;
+        lx = px - a.x0; ly = py - a.y0;
+        blk = (ly / 16u) * a.nbx + lx / 16u;
+    } else {
+        const uint32_t tile = (py / a.tile_h) * a.tiles_x + px / a.tile_w;
+        if (tile < a.first_tile || (tile - a.first_tile) % a.tile_stride) return;
+        const uint32_t j = (tile - a.first_tile) / a.tile_stride;
+        if (j >= a.n_tiles) return;
+        lx = px % a.tile_w; ly = py % a.tile_h;
+        blk = j * (a.nbx * a.nby) + (ly / 16u) * a.nbx + lx / 16u;
+    }
+    atomicAdd(&cost[blk * 4u + (((ly % 16u) / 8u) << 1) + ((lx % 16u) / 8u)], 1u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -287,6 +333,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_TILE_READY_MIN) { c->opt_tile_ready = std::min(64, std::max(1, value)); }
     else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
     else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
+    else if (option == GRT_OPT_COLD_ESTIMATE) { c->opt_cold_estimate = value ? 1 : 0; c->cost_valid = false; }
     else if (option == GRT_OPT_SIZE_CLASSES) { g_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
@@ -605,6 +652,22 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
         if (split) a.n_heavy = c->d_n_heavy;
+    } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && c->n && (a.mode == 0 || a.mode == 1)) {
+        // no costs of a previous frame with this geometry: order the tiles by the number of particle centres that
+        // project into them (dense tiles first), so that the first frame's long tiles do not start last
+        CHK(c, hipMemsetAsync(c->d_cost_dil, 0, sizeof(uint32_t) * n_units, s));
+        const uint32_t stride = c->n > 400000 ? 4u : 1u; // original (unsorted) order: every 4th particle is a fair sample
+        const uint32_t ns = ((uint32_t)c->n + stride - 1) / stride;
+        hipLaunchKernelGGL(k_estimate_costs, dim3((ns + 255) / 256), dim3(256), 0, s, c->d_pos, (uint32_t)c->n, stride, a, c->d_cost_dil);
+        const uint32_t* src = c->d_cost_dil;
+        if (a.mode == 0) { // proxies are a few tiles wide: a tile next to a dense one is heavy too
+            int rcd = dilate_unit_costs(c->d_cost_dil, c->d_cost, a.nbx, a.nby, 1, s, &c->err);
+            if (rcd != GRT_OK) return rcd;
+            src = c->d_cost;
+        }
+        int rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, s, &c->err);
+        if (rc != GRT_OK) return rc;
+        a.order = c->d_order;
     }
     CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
     a.cost = c->d_cost;

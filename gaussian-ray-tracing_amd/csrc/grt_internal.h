@@ -203,6 +203,7 @@ struct grt_ctx {
     int opt_feedback = 1;
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr;
     int opt_cost_radius = 4; // tiles; 0 = off
+    int opt_cold_estimate = 1; // order a frame without previous-frame costs by projected particle counts
     uint32_t cost_cap = 0;
     bool cost_valid = false;
     // wavefront buffers (allocated on first mesh frame)

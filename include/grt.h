@@ -142,7 +142,9 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_COST_RADIUS = 13       /* scheduling feedback under a moving camera: a tile's cost is the largest of last frame's costs
                                          within value tiles of it (default 4; 0 = the tile's own cost) */,
        GRT_OPT_SIZE_CLASSES = 14      /* 1 (default): proxies much larger than average get subtrees of their own in the Gaussian LBVH
-                                         (size class in the top Morton bits); 0: plain Morton order.  Process-wide; next build */ };
+                                         (size class in the top Morton bits); 0: plain Morton order.  Process-wide; next build */,
+       GRT_OPT_COLD_ESTIMATE = 15     /* 1 (default): a frame with no previous-frame costs (first frame, new size) launches its tiles in the
+                                         order of the number of particle centres projecting into them; 0: screen order */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
