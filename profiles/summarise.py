@@ -1,45 +1,82 @@
 #!/usr/bin/env python3
 """Summarises one profiles/collect.sh run into the small files kept under profiles/ (the raw rocprofv3 output stays
-in gpurun_out/).  Counters are averaged over the timed-loop dispatches of the render kernel (the instrumented and the
-cold-order frames bench.py runs first are skipped: only dispatches after the first 4 are used)."""
-import csv, glob, json, os, shutil, sys, collections
+in gpurun_out/).  Counters are averaged over the timed-loop dispatches of the render kernel (the instrumented frame
+bench.py runs first is skipped: only dispatches after the first 2 are used)."""
+import csv, datetime, glob, json, os, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-KERNEL = "k_render_stream<false, false, false>"
+KERNEL = "k_render_tile<false, false, false>"
 
 for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if "rocprim" not in r[0] and float(r[4]) >= 0.05][:12]
+    keep = [rows[0]] + [r for r in rows[1:] if "rocprim" not in r[0] and float(r[4]) >= 0.05][:14]
     with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w", newline="") as o:
         csv.writer(o).writerows(keep)
 for line in open(src + "/bench_under_rocprof.log"):
     if line.startswith("{"):
         open(os.path.join(here, f"{tag}_bench_under_rocprof.json"), "w").write(json.dumps(json.loads(line), indent=1) + "\n")
 
-out = {}
-for f in glob.glob(src + "/pmc*/**/*counter_collection.csv", recursive=True):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"]:
-            acc[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-    for name, d in acc.items():
-        v = [d[k] for k in sorted(d)][4:]
-        if v:
-            out[name] = sum(v) / len(v)
-res = {"kernel": "grt::" + KERNEL, "workload": "C3 (bench.py default), steady-state frames", "per_dispatch": out}
+def per_kernel(pattern, name_filter, skip):
+    out = {}
+    for f in glob.glob(pattern, recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f)):
+            if name_filter(r["Kernel_Name"], r):
+                acc[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+        for name, d in acc.items():
+            v = [d[k] for k in sorted(d)][skip:]
+            if v:
+                out[name] = sum(v) / len(v)
+    return out
+
+out = per_kernel(src + "/pmc*/**/*counter_collection.csv", lambda n, r: KERNEL in n, 2)
+res = {"kernel": "grt::" + KERNEL, "workload": "C3 (bench.py default), steady-state frames", "collected": datetime.date.today().isoformat(),
+       "per_dispatch": out}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     res["hbm_bytes_per_launch"] = int((2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024)  # MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE x2
     res["hbm_bytes_per_launch_raw"] = int((out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024)
 if "TCC_HIT_sum" in out:
     res["l2_hit_rate"] = round(out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]), 4)
+calib = None
+cpath = src + "/valu_calib.json"
+if os.path.exists(cpath):
+    cj = json.load(open(cpath))
+    json.dump(cj, open(os.path.join(here, f"{tag}_valu_calib.json"), "w"), indent=1)
+    calib = {(c["inst"], c["waves_per_simd"]): c for c in cj["cases"]}
 if "SQ_WAVES" in out and "SQ_INSTS_VALU" in out:
     w = out["SQ_WAVES"]
     res["per_wave"] = {k: round(v / w, 1) for k, v in out.items() if k.startswith("SQ_")}
-    # SQ cycle counters tick once per 4 clocks; a SIMD holds 4 of these waves (128 VGPRs): the VALU is busy for
-    # 4 * ACTIVE_INST_VALU of every WAVE_CYCLES a wave is resident
-    res["valu"] = {"valu_insts_per_wave": round(out["SQ_INSTS_VALU"] / w), "salu_insts_per_wave": round(out["SQ_INSTS_SALU"] / w),
-                   "valu_busy_frac": round(4 * out["SQ_ACTIVE_INST_VALU"] / out["SQ_WAVE_CYCLES"], 3),
-                   "note": "4 waves/SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc, same command"}
+    # What is 100 %?  The calibration microbenchmark (profiles/calib/valu_calib.hip) at the SAME residency (4 waves
+    # per SIMD): a SIMD issues one wave64 VALU instruction every 3.1 cycles from dependent chains, one every 2.0 from
+    # independent ones; this kernel's waves issue one every `cycles_per_valu_inst_per_simd` (SQ_WAVE_CYCLES counts
+    # quad-cycles of ONE wave; 4 waves share the SIMD).
+    cyc = 4.0 * out["SQ_WAVE_CYCLES"] / out["SQ_INSTS_VALU"] / 4.0
+    v = {"valu_insts_per_wave": round(out["SQ_INSTS_VALU"] / w), "salu_insts_per_wave": round(out["SQ_INSTS_SALU"] / w),
+         "waves_per_simd": 4,
+         "cycles_per_valu_inst_per_simd": round(cyc, 2),
+         "raw_metric_4x_ACTIVE_INST_VALU_over_WAVE_CYCLES": round(4 * out["SQ_ACTIVE_INST_VALU"] / out["SQ_WAVE_CYCLES"], 3)}
+    v["valu_pipe_utilisation"] = round(v["raw_metric_4x_ACTIVE_INST_VALU_over_WAVE_CYCLES"] / 2.0, 3)  # the SIMD-32 retires a wave64 op in 2 cycles
+    if calib:
+        dep = calib[("v_fma_f32_dependent", 4)]["cyc_per_inst_one_wave"] / 4.0
+        ind = calib[("v_fma_f32", 4)]["cyc_per_inst_one_wave"] / 4.0
+        mix = calib[("v_fma_f32+s_add_u32 interleaved (per pair)", 4)]["cyc_per_inst_one_wave"] / 4.0
+        v["calibration_cycles_per_inst_per_simd_at_4_waves"] = {"dependent_valu": round(dep, 2), "independent_valu": round(ind, 2),
+                                                                 "valu_salu_pair": round(mix, 2)}
+        v["valu_issue_frac_of_dependent_chain_rate"] = round(dep / cyc, 3)
+        v["valu_issue_frac_of_independent_rate"] = round(ind / cyc, 3)
+    cal = per_kernel(src + "/calib_pmc/**/*counter_collection.csv", lambda n, r: "k_fma_dep" in n or n.startswith("k_fma("), 0)
+    if cal.get("SQ_WAVE_CYCLES"):
+        v["raw_metric_of_the_saturating_microkernels_all_W"] = round(4 * cal["SQ_ACTIVE_INST_VALU"] / cal["SQ_WAVE_CYCLES"], 3)
+    v["note"] = ("rocprofv3 --pmc of the same command.  The raw metric round 1 quoted as 'VALU busy' (n_waves x SQ_ACTIVE_INST_VALU / "
+                 "SQ_WAVE_CYCLES) tops out at 2.0, not 1.0: the SIMD-32 retires a wave64 instruction every 2 cycles, so the VALU PIPE "
+                 "utilisation is half of it (valu_pipe_utilisation).  What bounds the kernel is the rate at which FOUR resident waves can "
+                 "issue dependent instructions (valu_issue_frac_of_dependent_chain_rate; calibration: profiles/calib/valu_calib.hip)")
+    res["valu"] = v
 json.dump(res, open(os.path.join(here, f"{tag}_counters.json"), "w"), indent=1)
+tpath = os.path.join(here, "traffic.json")
+tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+tj["C3_sh0_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
+                      "kernel": res["kernel"], "source": f"profiles/{tag}_counters.json"}
+json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(res, indent=1))
