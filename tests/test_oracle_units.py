@@ -208,7 +208,7 @@ def test_origin_inside_proxy_gives_exit_only():
 # ---------------------------------------------------------------------------------------------
 # bit-exact pins against the reference sources compiled in place (oracle/_ref)
 # ---------------------------------------------------------------------------------------------
-needs_ref = pytest.mark.skipif(O.ref() is None, reason="oracle/_ref/libgrt_ref.so not built")
+needs_ref = pytest.mark.skipif(not os.path.exists(O._REF), reason="oracle/_ref/libgrt_ref.so not built")  # (file check only: the .so is loaded by the CPU tests that use it, never at collection)
 
 
 @needs_ref
