@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             float Fbag = INFINITY;   // smallest lambda in the bag
             bool rebal = false;      // children were parked in the bag: re-split near / far before going on
             float F = 0.0f;
+            float Ff_cur = 0.0f; // minimum of the register part of the frontier (loop top)
             bool done = false;
 
             while (true) {
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     GRT_D(node_visits, 1)
                 } else {
                     float Ff = wave_min(fl);
+                    Ff_cur = Ff;
                     if (nbag) {
                         const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
                         // (everything but one entry may end up in the bag: only when frontier + bag fit it)
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                             Fbag = nfar ? wave_min(far_min) : INFINITY;
                             rebal = false;
                             Ff = wave_min(fl);
+                            Ff_cur = Ff;
                         }
                     }
                     F = fminf(Ff, Fbag);
@@ -523,16 +526,22 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     nref = cur;
                     gv = g == 0u;
                 } else {
-                    const float Fn = wave_min(rng_l ? INFINITY : fl); // nearest internal node (free slots hold inf)
-                    const float Fr = wave_min(rng_l ? fl : INFINITY); // nearest leaf range
+                    // (no reductions here: the frontier minimum Ff of the loop top and two votes decide the step)
+                    const bool have_rng = wave_any(rng_l);
                     // a nearly full frontier takes leaf steps whatever lies in front (testing particles early is always
                     // legal; spilling children to the depth-first stack stalls the front)
                     const uint32_t nocc = (uint32_t)__popcll(wave_ballot(occ_l));
-                    const bool crowded = (nocc > 64u - a.tile_reserve) && (Fr < INFINITY);
+                    const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
                     const float hz = F + F * a.tile_look;
-                    leaf_step = (Fr < INFINITY) && (!(Fn <= hz) || crowded);
+                    const bool node_near = wave_any(occ_l && !rng_l && (fl <= hz));
+                    leaf_step = have_rng && (!node_near || crowded);
+                    // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
+                    // reduction
+                    float Fr = Ff_cur, Fn = Ff_cur;
+                    if (leaf_step && !wave_any(rng_l && (fl <= Ff_cur))) Fr = wave_min(rng_l ? fl : INFINITY);
+                    if (!leaf_step && !node_near) Fn = wave_min(rng_l ? INFINITY : fl);
                     const float tau = leaf_step ? (Fr + Fr * a.tile_band) : fmaxf(hz, Fn);
                     const bool cand = occ_l && (rng_l == leaf_step);
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     if ((uint32_t)__popcll(sm) > maxb) {
                         // more candidates than the step can take: the NEAREST ones go first (four bisection steps on
                         // the distance threshold; lane order only breaks what is left of the tie)
-                        float lo_ = leaf_step ? Fr : Fn, hi_ = tau;
+                        float lo_ = wave_min(cand ? fl : INFINITY), hi_ = tau; // the nearest candidate itself always qualifies
                         for (int it = 0; it < 4; it++) {
                             const float mid = 0.5f * (lo_ + hi_);
                             const bool few = (uint32_t)__popcll(wave_ballot(cand && (fl <= mid))) <= maxb;
