@@ -45,7 +45,8 @@ constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kerne
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
 constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
 constexpr uint32_t kMaxIters = 1u << 21; // steps of one tile before the watchdog gives up (a heavy C3 tile takes ~2000)
-constexpr uint32_t kStack = 384u; // depth-first overflow stack (only when the LDS bag is full too)
+constexpr uint32_t kStack = 288u; // depth-first overflow stack (only when the LDS bag is full too; guarded).  LDS per wave
+                                  // must stay <= 10 KB: 10304 B gave 15 waves per CU instead of 16 and cost 4 %
 constexpr uint32_t kKeep = 40u;
 constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's overflow bag (entries of 16 B, in global memory)  // frontier entries kept in registers by a rebalance (the nearest ones)
 
