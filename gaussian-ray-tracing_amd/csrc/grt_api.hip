@@ -300,7 +300,7 @@ void grt_destroy(grt_ctx* c)
     (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
-    (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount);
+    (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -334,6 +334,13 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_TILE_BAND) { c->opt_tile_band = std::max(0, value); }
     else if (option == GRT_OPT_TILE_LOOKAHEAD) { c->opt_tile_look = std::max(0, value); }
     else if (option == GRT_OPT_COLD_ESTIMATE) { c->opt_cold_estimate = value ? 1 : 0; c->cost_valid = false; }
+    else if (option == GRT_OPT_BUNDLE_ROUNDS) {
+        if (value < 0 || value > kMaxBundleRounds) { c->err = "GRT_OPT_BUNDLE_ROUNDS must be 0.." + std::to_string(kMaxBundleRounds); return GRT_ERR_INVALID; }
+        c->opt_bundle_rounds = value;
+    }
+    else if (option == GRT_OPT_BUNDLE_BUDGET) { c->opt_bundle_budget = std::max(1, value); }
+    else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
+    else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { g_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
@@ -691,18 +698,29 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
     a.prec = nullptr; a.queue = nullptr; a.qcount = nullptr;
+    a.queue_in = nullptr; a.qcount_in = nullptr; a.queue_alt = nullptr;
+    a.heavy = nullptr; a.hcount = nullptr; a.fqueue = nullptr; a.fcount = nullptr; a.queue_in_packed = 0;
+    a.bundle_rounds = (uint32_t)c->opt_bundle_rounds;
+    a.bundle_budget = (uint32_t)c->opt_bundle_budget;
+    a.single_look = (float)c->opt_single_look / 1024.0f;
+    a.single_band = (float)c->opt_single_band / 1024.0f;
     if (c->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
         const size_t need = (size_t)a.n_blocks * 256;
         if (c->wf_cap < need) {
-            (void)hipFree(c->d_prec); (void)hipFree(c->d_queue);
-            c->d_prec = c->d_queue = nullptr;
+            (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
+            c->d_prec = c->d_queue = c->d_fqueue = nullptr;
+            c->d_heavy = nullptr;
             c->wf_cap = 0;
             CHK(c, hipMalloc(&c->d_prec, need * 3 * sizeof(float4)));
-            CHK(c, hipMalloc(&c->d_queue, need * 4 * sizeof(float4)));
+            CHK(c, hipMalloc(&c->d_queue, 2 * need * 4 * sizeof(float4))); // two queues: the stages ping-pong
+            CHK(c, hipMalloc(&c->d_heavy, need * sizeof(uint32_t)));
+            CHK(c, hipMalloc(&c->d_fqueue, need * 4 * sizeof(float4)));
             c->wf_cap = need;
         }
-        if (!c->d_qcount) CHK(c, hipMalloc(&c->d_qcount, sizeof(uint32_t)));
+        if (!c->d_qcount) CHK(c, hipMalloc(&c->d_qcount, sizeof(uint32_t) * kWfCounters));
         a.prec = c->d_prec; a.queue = c->d_queue; a.qcount = c->d_qcount;
+        a.queue_alt = c->d_queue + c->wf_cap * 4;
+        a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
     CHK(c, hipEventRecord(c->ev0, s));
     a.erec = nullptr;

@@ -112,9 +112,21 @@ struct RenderArgs {
     uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
     uint32_t ovf_chunks;     // chunks in the pool
     // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
-    float4* prec;      // [n_blocks*256][3] primary mesh-hit records
-    float4* queue;     // [n_blocks*256][4] compacted continuation rays
-    uint32_t* qcount;  // number of queued rays
+    float4* prec;      // [n_blocks*256][3] mesh-hit records: of the pixels (stage 1), later of the queue entries (stage 3)
+    float4* queue;     // [n_blocks*256][4] continuation rays this launch WRITES: 64-entry chunks, one per 8x8 tile that has
+                       // a ray going on, lane l in slot l (bit 31 of the timeout word = the slot carries a ray)
+    uint32_t* qcount;  // chunks written
+    const float4* queue_in;   // the queue this launch READS (stage 3: k_queue_mesh, bundle kernel, k_bounce)
+    const uint32_t* qcount_in;
+    float4* queue_alt;        // the second queue (launch_render ping-pongs between `queue` and this one)
+    uint32_t bundle_rounds;   // bounce iterations on the bundle kernel before k_bounce finishes the rest (tile kernel only)
+    uint32_t bundle_budget;   // steps a chunk may take on the bundle kernel before its rays are traced one per wave
+    uint32_t* heavy;          // [n_blocks*256] entries of queue_in whose chunk gave up (written by mode 1, read by mode 2)
+    uint32_t* hcount;
+    float4* fqueue;           // [n_blocks*256][4] PACKED queue of the lone rays that go on (read by k_bounce only)
+    uint32_t* fcount;
+    uint32_t queue_in_packed; // k_bounce: *qcount_in counts entries, not 64-entry chunks
+    float single_look, single_band; // look-ahead / band of the one-ray-per-wave mode
 };
 
 // second stream + events used to run the big-window kernel (heavy blocks) beside the default one
@@ -129,8 +141,12 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
                          std::string* err);
-int launch_render_tile(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err);
+int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 8;
+constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
+// counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
+// round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the packed queue of lone rays
+constexpr int kWfCounters = 2 * kMaxBundleRounds + 2;
 constexpr uint32_t kTileOvfEntries = 96; // GRT_TILE_OVF of grt_render_tile.hip
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
 // GRT_OPT_KERNEL values: 0 auto (tile kernel where it applies, else streaming), 1 per-lane, 2 round-based wave,
@@ -207,8 +223,13 @@ struct grt_ctx {
     uint32_t cost_cap = 0;
     bool cost_valid = false;
     // wavefront buffers (allocated on first mesh frame)
-    float4 *d_prec = nullptr, *d_queue = nullptr;
-    uint32_t* d_qcount = nullptr;
+    float4 *d_prec = nullptr, *d_queue = nullptr; // d_queue: two queues (ping-pong between the stages)
+    uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)
+    int opt_bundle_rounds = 2; // bounce iterations traced by the wave-per-bundle kernel before the per-lane kernel finishes
+    int opt_bundle_budget = 1024;
+    int opt_single_look = 1024, opt_single_band = 256; // 1/1024
+    uint32_t* d_heavy = nullptr;
+    float4* d_fqueue = nullptr;
     size_t wf_cap = 0;
     uint64_t cost_sig[6] = {0, 0, 0, 0, 0, 0};
     uint32_t* d_n_heavy = nullptr;

@@ -9,6 +9,7 @@
 // as 64-bit keys (t, particle id, entry<exit) + alpha.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 
 #include "grt_device.h"
@@ -345,10 +346,47 @@ __device__ __forceinline__ RayState fresh_ray(f3 o, f3 d)
 // stage 1 (this kernel): camera ray + mesh closest hit + closest-hit shading for every pixel, one record per thread
 //   prec[3*i+0] = (seg_tmax, flags, curO.x, curO.y)   flags = state | numBounces << 8 | have_ray << 16
 //   prec[3*i+1] = (curO.z, curD.x, curD.y, curD.z)     prec[3*i+2] = (normal.xyz, 0)
-// stage 2 (grt_render_stream.hip, MESH = true): the coherent primary Gaussian segment [t_min, seg_tmax] on the
-//   wave-cooperative streaming kernel, first iteration of the compositing, and COMPACTION of the rays that go
-//   on (wave ballot + popcount prefix + one atomicAdd per wave) into the continuation queue
-// stage 3 (k_bounce): the queued, now incoherent, rays finish their bounce loop on the per-lane traversal
+// stage 2 (grt_render_tile.hip / grt_render_stream.hip, MESH = true): the coherent primary Gaussian segment
+//   [t_min, seg_tmax] on the wave-per-tile kernel, first iteration of the compositing; the rays that go on are written
+//   to the continuation queue, one 64-entry chunk per tile (lane l in slot l)
+// stage 3, tile kernel only, bundle_rounds times: k_queue_mesh (the mesh hit of every queued ray, per lane; the mesh
+//   tree is small) + the tile kernel with BUNDLE = true (one wave per chunk: the bounced rays of a tile are still a
+//   bundle, their Gaussian segment is traced wave-cooperatively) -> the next queue
+// stage 4 (k_bounce): whatever is still going finishes its bounce loop on the per-lane traversal
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_queue_mesh(const RenderArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    Cnt c;
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; // queue entry
+    if ((uint32_t)(i >> 6) >= *a.qcount_in) return;             // wave-uniform: whole chunks
+    const float4 q0 = a.queue_in[i * 4], q1 = a.queue_in[i * 4 + 1], q3 = a.queue_in[i * 4 + 3];
+    const bool have_ray = (__float_as_uint(q3.y) >> 31) != 0u;
+    const f3 ray_o = mk3(q0.x, q0.y, q0.z), ray_d = mk3(q0.w, q1.x, q1.y);
+    int state = MeshPass;
+    float seg_tmax = a.p.t_max;
+    f3 normal = mk3(0, 0, 0), curO = mk3(0, 0, 0), curD = mk3(0, 0, 0);
+    uint32_t numBounces = __float_as_uint(q3.x);
+    if (have_ray) {
+        const MeshHit mh = mesh_closest<COUNT>(a, stk, ray_o, ray_d, kTraceMeshTmin, kTraceMeshTmax, c);
+        mesh_shade(a, mh, ray_o, ray_d, state, seg_tmax, normal, curO, curD, numBounces);
+    }
+    const uint32_t flags = (uint32_t)state | (numBounces << 8) | ((have_ray ? 1u : 0u) << 16);
+    a.prec[i * 3 + 0] = make_float4(seg_tmax, __uint_as_float(flags), curO.x, curO.y);
+    a.prec[i * 3 + 1] = make_float4(curO.z, curD.x, curD.y, curD.z);
+    a.prec[i * 3 + 2] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    if (COUNT) {
+        uint32_t x = c.node_visits;
+        for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+        if (lane == 0 && x) {
+            atomicAdd(&a.counters[4], (unsigned long long)x);
+            atomicAdd(&a.counters[6], (unsigned long long)x);
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_primary_mesh(const RenderArgs a)
 {
@@ -409,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_mesh(const RenderArgs a)
     }
 }
 
-// stage 3: finish the queued rays (queue record layout: see grt_render_stream.hip, enqueue)
+// stage 4: finish the queued rays (queue record layout: grt_render_tile.hip / grt_render_stream_body.inc, MESH epilogue)
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
 {
@@ -417,18 +455,19 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
     uint32_t* stk = lds_stack + threadIdx.x;
     Cnt c;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n = *a.qcount;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (blockIdx.x * kBlock >= n) return;
-    if (i < n) {
-        const float4 q0 = a.queue[(size_t)i * 4], q1 = a.queue[(size_t)i * 4 + 1], q2 = a.queue[(size_t)i * 4 + 2],
-                     q3 = a.queue[(size_t)i * 4 + 3];
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t n_ent = a.queue_in_packed ? (size_t)*a.qcount_in : (size_t)*a.qcount_in * 64u;
+    if (((size_t)blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= n_ent) return; // wave-uniform
+    float4 q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n_ent) q3 = a.queue_in[i * 4 + 3];
+    if ((__float_as_uint(q3.y) >> 31) != 0u) { // the slot carries a ray
+        const float4 q0 = a.queue_in[i * 4], q1 = a.queue_in[i * 4 + 1], q2 = a.queue_in[i * 4 + 2];
         RayState st;
         st.curO = mk3(q0.x, q0.y, q0.z);
         st.curD = mk3(q0.w, q1.x, q1.y);
         st.accumColor = mk3(q1.z, q1.w, q2.x);
         st.accumAlpha = q2.y; st.blocking = q2.z; st.density = q2.w;
-        st.numBounces = __float_as_uint(q3.x); st.timeout = __float_as_uint(q3.y);
+        st.numBounces = __float_as_uint(q3.x); st.timeout = __float_as_uint(q3.y) & 0x7FFFFFFFu;
         const size_t out_idx = (size_t)__float_as_uint(q3.z) | ((size_t)__float_as_uint(q3.w) << 32);
         const f3 col = shade_ray<COUNT, kBounceK>(a, stk, st, c);
         if (a.outf) {
@@ -543,7 +582,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
     if (streaming && a.mroot == kNoRoot)
-        return tile_kernel ? launch_render_tile(a, count, false, stream, err) : launch_render_stream(a, count, false, stream, aux, err);
+        return tile_kernel ? launch_render_tile(a, count, false, false, stream, err) : launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
     if (streaming) {
         if (!a.prec || !a.queue || !a.qcount) {
@@ -554,22 +593,49 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             if (err) *err = "BVH height " + std::to_string(stack_depth) + " needs more than 160 KiB of LDS stack";
             return GRT_ERR_LIMIT;
         }
-        hipError_t e = hipMemsetAsync(a.qcount, 0, sizeof(uint32_t), stream);
+        if (!a.queue_alt) {
+            if (err) *err = "wavefront pipeline: continuation buffers missing";
+            return GRT_ERR_INVALID;
+        }
+        // counters of the pipeline: see kWfCounters (grt_internal.h)
+        hipError_t e = hipMemsetAsync(a.qcount, 0, sizeof(uint32_t) * kWfCounters, stream);
         auto fp = count ? k_primary_mesh<true> : k_primary_mesh<false>;
+        auto fq = count ? k_queue_mesh<true> : k_queue_mesh<false>;
         auto fb = count ? k_bounce<true> : k_bounce<false>;
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             if (err) *err = std::string("wavefront setup: ") + hipGetErrorString(e);
             return GRT_ERR_HIP;
         }
         hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
-        int rc = tile_kernel ? launch_render_tile(a, count, true, stream, err) : launch_render_stream(a, count, true, stream, aux, err);
+        int rc = tile_kernel ? launch_render_tile(a, count, true, 0, stream, err) : launch_render_stream(a, count, true, stream, aux, err);
         if (rc != GRT_OK) return rc;
         RenderArgs b = a;
         b.order = nullptr;
         b.cost = nullptr;
+        float4* q[2] = {a.queue, a.queue_alt};
+        uint32_t in = 0, stage = 0;
+        const uint32_t rounds = tile_kernel ? std::min<uint32_t>(a.bundle_rounds, (uint32_t)kMaxBundleRounds) : 0u;
+        b.fcount = a.qcount + 2 * kMaxBundleRounds + 1;
+        for (uint32_t r = 0; r < rounds; r++) {
+            b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
+            b.queue = q[in ^ 1u]; b.qcount = a.qcount + stage + 1u;
+            b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
+            hipLaunchKernelGGL(fq, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+            rc = launch_render_tile(b, count, true, 1, stream, err);
+            if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err);
+            if (rc != GRT_OK) return rc;
+            in ^= 1u;
+            stage++;
+        }
+        b.queue_in = q[in]; b.qcount_in = a.qcount + stage; b.queue_in_packed = 0;
         hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+        if (rounds) { // the lone rays that still bounce
+            b.queue_in = a.fqueue; b.qcount_in = b.fcount; b.queue_in_packed = 1;
+            hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) {
             if (err) *err = std::string("wavefront launch: ") + hipGetErrorString(e);

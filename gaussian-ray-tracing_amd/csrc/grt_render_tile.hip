@@ -53,6 +53,9 @@ constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's 
 #ifndef GRT_TILE_WAVES
 #define GRT_TILE_WAVES 4
 #endif
+#ifndef GRT_BISECT
+#define GRT_BISECT 18 /* most bisection steps of a nearest-k selection (4 / 6 at least) */
+#endif
 #define GRT_KS 12
 #define KS 12
 #define KLAST k11
@@ -60,6 +63,7 @@ constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's 
 #include "grt_slots_gen.inc"
 #define PL_OTHER(cell) pl_other[(cell) * kWG + lane]
 #define PL_ALPHA(cell) pl_alpha[(cell) * kWG + lane]
+#define PL_COL(cell, ch) pl_col[((ch) * KS + (cell)) * kWG + lane]
 
 // Diagnostic build (make EXTRA=-DGRT_TILE_DIAG, never shipped; counters on): the counters hold WAVE-level trip counts —
 // rays: node steps, segments: particles fetched, hit_evals: compositing steps, rounds: passes, node_visits: depth-first
@@ -105,6 +109,23 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m) // number of set bit
     return 0u;
 #endif
 }
+// wave64 minimum of 64-bit keys (two unsigned 32-bit DPP reductions: wave_min works on the bit patterns)
+__device__ __forceinline__ uint64_t wave_umin64(uint64_t k)
+{
+    const uint32_t hi = (uint32_t)(k >> 32);
+    const uint32_t mh = __float_as_uint(wave_min(__uint_as_float(hi)));
+    const uint32_t lo = (hi == mh) ? (uint32_t)k : 0xFFFFFFFFu;
+    const uint32_t ml = __float_as_uint(wave_min(__uint_as_float(lo)));
+    return ((uint64_t)mh << 32) | (uint64_t)ml;
+}
+__device__ __forceinline__ float lane_value(float v, int l) // v of lane l (l wave-uniform)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+#else
+    return v;
+#endif
+}
 __device__ __forceinline__ void wave_fence()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -112,27 +133,56 @@ __device__ __forceinline__ void wave_fence()
 #endif
 }
 
-template <bool COUNT, bool SH, bool MESH>
-__global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const RenderArgs a)
+// BUNDLE = true (stage 3 of the mesh wavefront pipeline): the wave's 64 rays are one chunk of the continuation queue —
+// the rays of one 8x8 tile after their bounce, each with its own origin.  The frustum planes get offsets (each plane is
+// pushed out to the outermost origin), the distance bounds are taken about the first ray's origin and loosened by the
+// origins' spread, and a pass only takes the rays within ~16 degrees of its first ray (the others wait for a later pass),
+// so that the bundle's frustum stays a useful cull.  The per-eye records do not apply: A (o - mu) is formed per lane.
+// A bundle that is not one — rays spread wide AND through dense parts of the scene — makes every step pay for 64 rays that
+// share nothing.  MODE 1 therefore works to a budget of steps: a chunk that exceeds it gives up, nothing of it is kept, and
+// its rays go on the `heavy` list; MODE 2 traces the rays of that list ONE PER WAVE, a fixed grid striding over the list.
+// There every lane holds the same ray, and the exact work turns round as well: LANES = PARTICLES.  The (<= 64) particles
+// of a leaf step are slab-tested at once, each by the lane that culled its box (record by vector loads); a hit goes into
+// THAT lane's window together with its colour, so the 64 windows are one pool of 768 pending events; compositing takes
+// the smallest key of the pool (one 64-bit wave minimum per event) and updates the wave-uniform T / radiance.  A ray with
+// a thousand events is then a few dozen steps, not a thousand — it is these rays that bound a per-lane or per-bundle
+// kernel's run time.  Same arithmetic per event, same order: same bits.
+template <bool COUNT, bool SH, bool MESH, int MODE>
+__global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_tile(const RenderArgs a)
 {
-    const uint32_t rank = xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
+    constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
+    const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
+    const uint32_t n_in = BUNDLE ? (SINGLE ? *a.hcount : *a.qcount_in) : 0u; // chunks of the queue / rays of the heavy list
+    const uint32_t lane = threadIdx.x;
     __shared__ float pl_other[KS * kWG], pl_alpha[KS * kWG];
+    __shared__ float pl_col[SINGLE ? 3 * KS * kWG : 1]; // MODE 2: the event's radiance, fetched by the lane that inserted it
+    (void)pl_col;
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
     __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + 3 siblings per level
                                  // below it (<= 3 * 62 for the tree heights the launcher sends here)
+    for (uint32_t unit_s = rank;; unit_s += gridDim.x) { // (one trip; MODE 2: a stride over the heavy list)
+    if (BUNDLE && unit_s >= n_in) break; // wave-uniform
     Cnt c, w;
     (void)w;
-    const uint32_t unit = a.order ? a.order[rank] : rank;
+    const uint32_t unit = (a.order && !BUNDLE) ? a.order[rank] : unit_s;
     // the heaviest tiles of the previous frame (the head of the cost-sorted order) bound the frame: they issue first
-    if (a.order && a.tile_prio_div && rank < gridDim.x / a.tile_prio_div) __builtin_amdgcn_s_setprio(2);
-    const uint32_t blk = unit >> 2, wave = unit & 3u, lane = threadIdx.x;
+    if (!BUNDLE && a.order && a.tile_prio_div && rank < gridDim.x / a.tile_prio_div) __builtin_amdgcn_s_setprio(2);
+    const uint32_t blk = unit >> 2, wave = unit & 3u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
-    uint32_t px, py;
-    size_t out_idx;
-    bool in_frame;
-    if (a.mode == 0) {
+    uint32_t px = 0, py = 0;
+    size_t out_idx = 0;
+    bool in_frame = false;
+    bool aborted = false; // MODE 1: over the step budget
+    // BUNDLE: this lane's entry of the incoming queue (MODE 2: the wave's ONE ray, on lane 0)
+    const size_t ent = SINGLE ? (size_t)a.heavy[unit] : (size_t)unit * 64u + lane;
+    const size_t qi = ent * 4;
+    if (BUNDLE) {
+        const float4 q3 = a.queue_in[qi + 3];
+        in_frame = (__float_as_uint(q3.y) >> 31) != 0u; // lanes that carry a ray (MODE 2: all 64 hold the SAME ray)
+        out_idx = (size_t)__float_as_uint(q3.z) | ((size_t)__float_as_uint(q3.w) << 32);
+    } else if (a.mode == 0) {
         px = a.x0 + (blk % a.nbx) * 16u + lx;
         py = a.y0 + (blk / a.nbx) * 16u + ly;
         in_frame = (px < a.x1) && (py < a.y1);
@@ -148,13 +198,22 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         in_frame = (px < a.p.width) && (py < a.p.height);
         out_idx = ((size_t)j * a.tile_h + oy) * a.tile_w + ox;
     }
-    const bool write = in_frame || (a.mode == 1);
+    const bool write = BUNDLE ? (in_frame && (!SINGLE || lane == 0u)) : (in_frame || (a.mode == 1));
+    const bool tally = !SINGLE || lane == 0u; // per-ray counters: once per ray
     const f3 nU = mk3(-a.p.U[0], -a.p.U[1], -a.p.U[2]), nV = mk3(-a.p.V[0], -a.p.V[1], -a.p.V[2]);
     const f3 W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
-    const f3 o = mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]); // wave-uniform origin (camera rays)
+    f3 o = mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]); // wave-uniform origin (camera rays); per lane when BUNDLE
     f3 d = mk3(0.0f, 0.0f, -1.0f);
     bool have_ray = in_frame;
-    if (in_frame) {
+    float density_in = 0.0f;
+    if (BUNDLE) {
+        if (in_frame) {
+            const float4 q0 = a.queue_in[qi], q1 = a.queue_in[qi + 1], q2 = a.queue_in[qi + 2];
+            o = mk3(q0.x, q0.y, q0.z);
+            d = mk3(q0.w, q1.x, q1.y);
+            density_in = q2.w;
+        }
+    } else if (in_frame) {
         if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
         else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
     }
@@ -163,8 +222,8 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
     float seg_tmax = a.p.t_max;
     uint32_t pflags = 0;
     f3 nextO = mk3(0, 0, 0), nextD = mk3(0, 0, 0), hitN = mk3(0, 0, 0);
-    if (MESH) { // stage 1 (k_primary_mesh) already traced the mesh for this pixel
-        const size_t pi = ((size_t)blk * kBlock + wave * 64u + lane) * 3;
+    if (MESH) { // stage 1 (k_primary_mesh / k_queue_mesh) already traced the mesh for this ray
+        const size_t pi = BUNDLE ? ent * 3 : ((size_t)blk * kBlock + wave * 64u + lane) * 3;
         const float4 pr0 = a.prec[pi], pr1 = a.prec[pi + 1], pr2 = a.prec[pi + 2];
         seg_tmax = pr0.x;
         pflags = __float_as_uint(pr0.y);
@@ -176,9 +235,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
 
     // ---- trace() for the whole wave (shaders/tracer.cuh:328-373), density starts at 0 ----
     const float minT = a.p.minTransmittance;
-    float T = 1.0f;
+    float T = 1.0f - density_in; // the payload's density carries over from segment to segment (shaders/tracer.cuh:331)
     f3 radiance = mk3(0.0f, 0.0f, 0.0f);
-    if (COUNT && have_ray) c.segments++;
+    if (COUNT && have_ray && tally) c.segments++;
     const uint64_t raym = wave_ballot(have_ray);
     if (a.root_ref != kNoRoot && raym) {
         const float epsT = 1e-9f;
@@ -189,14 +248,19 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         // ---- the tile's frustum (wave-uniform; culling only) ----
         // axis = direction of the first lane that has a ray; (u, v) complete it; a lane's direction is
         // d ~ ax + tu u + tv v, and the four planes bound (tu, tv) over the lanes, widened by 1e-4 rad.
-        const int l0 = (int)__builtin_ctzll(raym);
-        const f3 ax = mk3(__shfl(d.x, l0), __shfl(d.y, l0), __shfl(d.z, l0));
-        f3 e_;
-        {
-            const float axx = fabsf(ax.x), ayy = fabsf(ax.y), azz = fabsf(ax.z);
-            e_ = (axx <= ayy && axx <= azz) ? mk3(1, 0, 0) : ((ayy <= azz) ? mk3(0, 1, 0) : mk3(0, 0, 1));
+        f3 ax, uu, vv;
+        f3 oc = o; // the point the boxes are measured from: the eye; BUNDLE: the origin of the pass's first ray
+#define GRT_AXES(MASK)                                                                                     \
+        {                                                                                                  \
+            const int l0 = (int)__builtin_ctzll(MASK);                                                     \
+            ax = mk3(__shfl(d.x, l0), __shfl(d.y, l0), __shfl(d.z, l0));                                   \
+            if (BUNDLE) oc = mk3(__shfl(o.x, l0), __shfl(o.y, l0), __shfl(o.z, l0));                       \
+            const float axx = fabsf(ax.x), ayy = fabsf(ax.y), azz = fabsf(ax.z);                           \
+            const f3 e_ = (axx <= ayy && axx <= azz) ? mk3(1, 0, 0) : ((ayy <= azz) ? mk3(0, 1, 0) : mk3(0, 0, 1)); \
+            uu = normalize3(cross3(ax, e_));                                                               \
+            vv = cross3(ax, uu);                                                                           \
         }
-        const f3 uu = normalize3(cross3(ax, e_)), vv = cross3(ax, uu);
+        GRT_AXES(raym)
         // The frustum bounds the lanes that still WANT something (GRT_FRUSTUM(mask)): all rays at first; re-fitted when
         // half of them have finished (saturated, or past their window cut-off), so that a few straggling rays do not
         // drag the whole tile's frustum through the rest of the scene.
@@ -204,12 +268,27 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         float ivx, ivy, ivz; // per-axis slab bound: when every ray moves the same way along an axis,
                              // t >= (near plane - eye) / (largest |d|); 0 when the directions straddle the axis
         bool shx, shy, shz;  // near plane is the box's hi side
-#define GRT_AXIS(M, C, IV, SH_)                                                                            \
+        // BUNDLE only (all zero / one for camera rays): plane offsets mP = min over the rays of n_P . (o - oc) (<= 0: a ray
+        // stays on the inner side of the plane through ITS origin), per-axis origin offsets, the origins' spread about oc
+        // and the bounds of |d| (a bounced direction is a unit vector only up to rounding)
+        float mL = 0.0f, mR = 0.0f, mB = 0.0f, mT = 0.0f, ofx = 0.0f, ofy = 0.0f, ofz = 0.0f, rmax = 0.0f, idmax = 1.0f, idmin = 1.0f;
+#define GRT_AXIS(M, C, IV, SH_, OF)                                                                        \
         {                                                                                                  \
             const float mn_ = uni(wave_fmin((M) ? d.C : INFINITY)), mx_ = uni(wave_fmax((M) ? d.C : -INFINITY)); \
             SH_ = mx_ < -1e-20f;                                                                           \
             IV = (mn_ > 1e-20f) ? (1.0f - 1e-6f) / mx_ : (SH_ ? (1.0f - 1e-6f) / mn_ : 0.0f);              \
             IV = uni(pk_ * IV);                                                                            \
+            if (BUNDLE) { /* the origin nearest to the box side the rays enter through */                  \
+                const float dl_ = o.C - oc.C;                                                              \
+                const float q_ = SH_ ? uni(wave_fmin((M) ? dl_ : INFINITY)) : uni(wave_fmax((M) ? dl_ : -INFINITY)); \
+                OF = SH_ ? (q_ - 2e-6f * fabsf(q_) - 1e-30f) : (q_ + 2e-6f * fabsf(q_) + 1e-30f);          \
+            }                                                                                              \
+        }
+#define GRT_POFF(M, P, MP)                                                                                 \
+        {                                                                                                  \
+            const float dx_ = o.x - oc.x, dy_ = o.y - oc.y, dz_ = o.z - oc.z;                              \
+            const float s_ = P##x * dx_ + P##y * dy_ + P##z * dz_ - 8e-6f * ((fabsf(dx_) + fabsf(dy_)) + fabsf(dz_)); \
+            MP = uni(wave_fmin((M) ? s_ : INFINITY));                                                      \
         }
 #define GRT_FRUSTUM(M)                                                                                     \
         {                                                                                                  \
@@ -226,9 +305,16 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
             pRx = uni(pk_ * (tu1 * ax.x - uu.x)); pRy = uni(pk_ * (tu1 * ax.y - uu.y)); pRz = uni(pk_ * (tu1 * ax.z - uu.z)); \
             pBx = uni(pk_ * (vv.x - tv0 * ax.x)); pBy = uni(pk_ * (vv.y - tv0 * ax.y)); pBz = uni(pk_ * (vv.z - tv0 * ax.z)); \
             pTx = uni(pk_ * (tv1 * ax.x - vv.x)); pTy = uni(pk_ * (tv1 * ax.y - vv.y)); pTz = uni(pk_ * (tv1 * ax.z - vv.z)); \
-            GRT_AXIS(M, x, ivx, shx)                                                                       \
-            GRT_AXIS(M, y, ivy, shy)                                                                       \
-            GRT_AXIS(M, z, ivz, shz)                                                                       \
+            GRT_AXIS(M, x, ivx, shx, ofx)                                                                  \
+            GRT_AXIS(M, y, ivy, shy, ofy)                                                                  \
+            GRT_AXIS(M, z, ivz, shz, ofz)                                                                  \
+            if (BUNDLE) {                                                                                  \
+                GRT_POFF(M, pL, mL) GRT_POFF(M, pR, mR) GRT_POFF(M, pB, mB) GRT_POFF(M, pT, mT)            \
+                const float r_ = length3(sub3(o, oc)), ld_ = length3(d);                                   \
+                rmax = uni(wave_fmax((M) ? r_ : 0.0f)) * (1.0f + 4e-6f) + 1e-30f;                          \
+                idmax = 1.0f / (uni(wave_fmax((M) ? ld_ : 0.0f)) * (1.0f + 4e-6f));                        \
+                idmin = (1.0f + 4e-6f) / uni(wave_fmin((M) ? ld_ : INFINITY));                             \
+            }                                                                                              \
         }
 
         uint64_t last_key = mk_skey(a.p.t_min + epsT, 0x03FFFFFFu, 1) | kCellMask; // last composited event (exclusive bound)
@@ -239,15 +325,25 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                  k10 = kKeyInvalid, k11 = kKeyInvalid;
         uint32_t pmask = 0; // payload cells in use
         uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
+        uint32_t work = 0;  // MODE 1: particles fetched + 2 x exact tests run (wave-uniform), against the budget
         bool watchdog = false;
 #ifdef GRT_TILE_CHECK
         uint32_t dbg_n = 0, dbg_m = 0;
 #endif
         uint32_t chunk = kNoRoot; // this tile's chunk of the overflow pool (taken at the first window overflow)
-        const uint32_t ready_min = a.tile_ready_min; // lanes with a final event before a compositing sweep starts
+        const uint32_t ready_min = SINGLE ? 1u : a.tile_ready_min; // lanes with a final event before a compositing sweep starts
+        // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
+        const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;
 
         while (wave_any(alive)) { // one iteration = one front-to-back pass
-            if (COUNT && alive) c.rounds++;
+            bool parked = false; // BUNDLE: alive, but outside this pass's cone of directions
+            if (BUNDLE) {
+                GRT_AXES(wave_ballot(alive))
+                const bool in_cone = dot3(d, ax) >= 0.96f * length3(d) * length3(ax);
+                parked = alive && !in_cone;
+                alive = alive && in_cone;
+            }
+            if (COUNT && alive && tally) c.rounds++;
             GRT_D(rounds, 1)
             const uint64_t pass_lo = last_key; // events with key <= pass_lo were composited by an earlier pass
             const float t_lo = key_t(pass_lo);
@@ -295,7 +391,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     if (nbag) {
                         const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
                         // (everything but one entry may end up in the bag: only when frontier + bag fit it)
-                        if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * a.tile_look) && (nocc_ + 8u <= kKeep))) &&
+                        if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * look_) && (nocc_ + 8u <= kKeep))) &&
                             (nocc_ + nbag <= kBag)) {
                             // ---- rebalance: the nearest kKeep entries of (frontier + bag) stay in registers, the rest
                             //      goes (back) to the bag.  Everything passes through registers: 4 bag entries per lane.
@@ -319,7 +415,9 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                                             f2 = (bl1 < INFINITY) ? bl1 : 0.0f, f3 = (bl2 < INFINITY) ? bl2 : 0.0f,
                                             f4 = (bl3 < INFINITY) ? bl3 : 0.0f;
                                 float lo_ = lo0, hi_ = uni(wave_fmax(fmaxf(fmaxf(f0, f1), fmaxf(f2, fmaxf(f3, f4)))));
-                                for (int it = 0; it < 6; it++) {
+                                // (up to GRT_BISECT steps, until at least half of kKeep qualify: in a dense cluster hundreds of
+                                //  entries lie within 1e-3 of each other while the farthest one stretches the interval)
+                                for (int it = 0; it < GRT_BISECT; it++) {
                                     const float mid = 0.5f * (lo_ + hi_);
                                     const uint32_t n_ = (uint32_t)__popcll(wave_ballot(fl <= mid)) + (uint32_t)__popcll(wave_ballot(bl0 <= mid)) +
                                                         (uint32_t)__popcll(wave_ballot(bl1 <= mid)) + (uint32_t)__popcll(wave_ballot(bl2 <= mid)) +
@@ -327,6 +425,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                                     const bool few = n_ <= kKeep;
                                     lo_ = few ? mid : lo_;
                                     hi_ = few ? hi_ : mid;
+                                    if (few && n_ * 2u >= kKeep && it >= 5) break;
                                 }
                                 th = lo_;
                             }
@@ -396,7 +495,40 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
 
                 // ---- composite buffered events with t < F (and key < cutoff), in key order; deferred until
                 //      ready_min lanes have one, a window is nearly full, or the pass is over ----
-                if (!dfs) {
+                if (SINGLE && !dfs) {
+                    // ---- MODE 2: the pool's smallest final key, one event per trip; T / radiance are wave-uniform ----
+                    while (true) {
+                        const bool cl_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < lost);
+                        if (!wave_any(cl_)) break;
+                        GRT_D(hit_evals, 1)
+                        const uint64_t ek = wave_umin64(cl_ ? k0 : kKeyInvalid);
+                        const bool own = cl_ && (k0 == ek); // exactly one lane: a particle is tested once per pass
+                        const uint64_t om = wave_ballot(own);
+                        const int ol = (int)__builtin_ctzll(om);
+                        const uint32_t cell = (uint32_t)(ek & kCellMask);
+                        const uint32_t id = skey_id(ek);
+                        float ea = 0.0f, eo = INFINITY, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                        if (own) { ea = PL_ALPHA(cell); eo = PL_OTHER(cell); cr = PL_COL(cell, 0); cg = PL_COL(cell, 1); cb = PL_COL(cell, 2); }
+                        SLOT_SHIFT_ALL(om)
+                        ea = lane_value(ea, ol); eo = lane_value(eo, ol);
+                        cr = lane_value(cr, ol); cg = lane_value(cg, ol); cb = lane_value(cb, ol);
+                        if (COUNT && tally) c.hit_evals++;
+                        last_key = ek | kCellMask;
+                        if (a.p.alpha_min < ea) { // shaders/tracer.cuh:352-367
+                            radiance = add3(radiance, mul3s(mul3s(mk3(cr, cg, cb), T), ea));
+                            T *= (1.0f - ea);
+                        }
+                        if (!(T > minT)) alive = false;
+                        const bool rekey = own && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
+                        const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
+                        pmask = (own && !rekey) ? (pmask & ~(1u << cell)) : pmask;
+                        if (wave_any(rekey)) { // wave-uniform branch
+                            if (rekey) PL_OTHER(cell) = INFINITY;
+                            SLOT_INSERT(nk) // a slot was just freed: it fits
+                        }
+                    }
+                }
+                if (!SINGLE && !dfs) {
                     bool sweep = done;
                     while (true) {
                         const bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
@@ -510,6 +642,10 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     watchdog = true;
                     break;
                 }
+                if (MODE == 1 && iters + work > a.bundle_budget) { // not a bundle worth the name: its rays go one per wave
+                    aborted = true;
+                    break;
+                }
 
                 // ---- one step: the entries at the front, four lanes each.  LEAF step: leaf ranges -> their particles'
                 //      boxes are culled here and the survivors slab-tested at once (lanes = rays).  NODE step: internal
@@ -535,7 +671,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
-                    const float hz = F + F * a.tile_look;
+                    const float hz = F + F * look_;
                     const bool node_near = wave_any(occ_l && !rng_l && (fl <= hz));
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
@@ -543,7 +679,7 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     float Fr = Ff_cur, Fn = Ff_cur;
                     if (leaf_step && !wave_any(rng_l && (fl <= Ff_cur))) Fr = wave_min(rng_l ? fl : INFINITY);
                     if (!leaf_step && !node_near) Fn = wave_min(rng_l ? INFINITY : fl);
-                    const float tau = leaf_step ? (Fr + Fr * a.tile_band) : fmaxf(hz, Fn);
+                    const float tau = leaf_step ? (Fr + Fr * band_) : fmaxf(hz, Fn);
                     const bool cand = occ_l && (rng_l == leaf_step);
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
                     // one node: a frontier full of internal nodes overflows to the depth-first stack)
@@ -556,11 +692,15 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                         // more candidates than the step can take: the NEAREST ones go first (four bisection steps on
                         // the distance threshold; lane order only breaks what is left of the tie)
                         float lo_ = wave_min(cand ? fl : INFINITY), hi_ = tau; // the nearest candidate itself always qualifies
-                        for (int it = 0; it < 4; it++) {
+                        // (MODE 2 looks far ahead: bisect between the nearest and the farthest candidate, twice as finely)
+                        if (SINGLE) hi_ = fminf(tau, uni(wave_fmax((cand && (fl <= tau)) ? fl : 0.0f)));
+                        for (int it = 0; it < GRT_BISECT; it++) {
                             const float mid = 0.5f * (lo_ + hi_);
-                            const bool few = (uint32_t)__popcll(wave_ballot(cand && (fl <= mid))) <= maxb;
+                            const uint32_t n_ = (uint32_t)__popcll(wave_ballot(cand && (fl <= mid)));
+                            const bool few = n_ <= maxb;
                             lo_ = few ? mid : lo_;
                             hi_ = few ? hi_ : mid;
+                            if (few && n_ * 2u >= maxb && it >= 3) break;
                         }
                         th = lo_;
                         sm = wave_ballot(cand && (fl <= th));
@@ -593,28 +733,35 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     lim_dirty = false;
                 }
                 // box relative to the eye
-                const float lx_ = b0.x - o.x, ly_ = b0.y - o.y, lz_ = b0.z - o.z;
-                const float hx_ = b1.x - o.x, hy_ = b1.y - o.y, hz_ = b1.z - o.z;
+                const float lx_ = b0.x - oc.x, ly_ = b0.y - oc.y, lz_ = b0.z - oc.z;
+                const float hx_ = b1.x - oc.x, hy_ = b1.y - oc.y, hz_ = b1.z - oc.z;
                 // four frustum planes, each at the box corner farthest along its normal (wave-uniform choice); the
                 // slack covers the rounding of the three products (|n| < 2): 1e-5 x the L1 size of the box about the eye
                 const float epsM = -1e-5f * (((fabsf(lx_) + fabsf(hx_)) + (fabsf(ly_) + fabsf(hy_))) + (fabsf(lz_) + fabsf(hz_)));
-#define GRT_PSIDE(P)                                                                                       \
+#define GRT_PSIDE(P, MP)                                                                                   \
                 (__builtin_fmaf(P##x, (P##x >= 0.0f) ? hx_ : lx_,                                          \
-                 __builtin_fmaf(P##y, (P##y >= 0.0f) ? hy_ : ly_, P##z * ((P##z >= 0.0f) ? hz_ : lz_))) >= epsM)
-                const bool inside = GRT_PSIDE(pL) && GRT_PSIDE(pR) && GRT_PSIDE(pB) && GRT_PSIDE(pT);
+                 __builtin_fmaf(P##y, (P##y >= 0.0f) ? hy_ : ly_, P##z * ((P##z >= 0.0f) ? hz_ : lz_))) >= (BUNDLE ? epsM + (MP) : epsM))
+                const bool inside = GRT_PSIDE(pL, mL) && GRT_PSIDE(pR, mR) && GRT_PSIDE(pB, mB) && GRT_PSIDE(pT, mT);
 #undef GRT_PSIDE
                 // lower bound of t over the tile: Euclidean distance to the box, and the per-axis slab bound
                 const float ex_ = fmaxf(fmaxf(lx_, -hx_), 0.0f), ey_ = fmaxf(fmaxf(ly_, -hy_), 0.0f),
                             ez_ = fmaxf(fmaxf(lz_, -hz_), 0.0f);
-                const float euc = sqrtf(__builtin_fmaf(ex_, ex_, __builtin_fmaf(ey_, ey_, ez_ * ez_)));
-                const float sx_ = (shx ? hx_ : lx_) * ivx, sy_ = (shy ? hy_ : ly_) * ivy, sz_ = (shz ? hz_ : lz_) * ivz;
+                float euc = sqrtf(__builtin_fmaf(ex_, ex_, __builtin_fmaf(ey_, ey_, ez_ * ez_)));
+                float sx_, sy_, sz_;
+                if (BUNDLE) { // |d| t >= dist(o, box) >= dist(oc, box) - |o - oc|;  t >= (side - o.x) / d.x per axis
+                    euc = fmaxf(euc - rmax, 0.0f) * idmax;
+                    sx_ = ((shx ? hx_ : lx_) - ofx) * ivx; sy_ = ((shy ? hy_ : ly_) - ofy) * ivy; sz_ = ((shz ? hz_ : lz_) - ofz) * ivz;
+                } else {
+                    sx_ = (shx ? hx_ : lx_) * ivx; sy_ = (shy ? hy_ : ly_) * ivy; sz_ = (shz ? hz_ : lz_) * ivz;
+                }
                 float lam = fmaxf(fmaxf(euc, sx_), fmaxf(sy_, sz_)) * (1.0f - 2e-6f);
                 lam = fmaxf(lam, F); // never below the current front (keeps the frontier monotone)
                 bool want = valid && inside && (lam <= LIM);
                 if (LO > 0.0f) { // later passes: skip what ends before the restart point
                     const float fx_ = fmaxf(fabsf(lx_), fabsf(hx_)), fy_ = fmaxf(fabsf(ly_), fabsf(hy_)),
                                 fz_ = fmaxf(fabsf(lz_), fabsf(hz_));
-                    const float far = sqrtf(__builtin_fmaf(fx_, fx_, __builtin_fmaf(fy_, fy_, fz_ * fz_))) * (1.0f + 2e-6f);
+                    float far = sqrtf(__builtin_fmaf(fx_, fx_, __builtin_fmaf(fy_, fy_, fz_ * fz_))) * (1.0f + 2e-6f);
+                    if (BUNDLE) far = (far + rmax) * idmin;
                     want = want && (far >= LO);
                 }
                 uint64_t wm = wave_ballot(want);
@@ -622,35 +769,63 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 if (leaf_step) {
                     GRT_D(fetches, 1)
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
-                    while (wm) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(wm);
-                        wm &= wm - 1ull;
-                        const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
+                    bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
+                    while (SINGLE ? trip : (wm != 0ull)) {
+                        trip = false;
+                        float4 r0, r1, r2, r3, e0, e1, e2, e3;
+                        bool act_; // lanes the exact test is meant for
+                        if (SINGLE) { // every surviving lane fetches and tests ITS particle
+                            act_ = want && alive;
+                            r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (act_) {
+                                const float4* rp = a.rec + (size_t)cref * 4;
+                                r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+                            }
+                            if (COUNT) c.fetches += 4u * (uint32_t)__popcll(wm);
+                            wm = 0ull;
+                        } else {
+                            const uint32_t b = (uint32_t)__builtin_ctzll(wm);
+                            wm &= wm - 1ull;
+                            const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
+                            const uint32_t ridx = pidx * 4u;
+                            r0 = sload4(a.rec, ridx); r1 = sload4(a.rec, ridx + 1); r2 = sload4(a.rec, ridx + 2);
+                            r3 = sload4(a.rec, ridx + 3);
+                            if (!BUNDLE) {
+                                e0 = sload4(a.erec, ridx); e1 = sload4(a.erec, ridx + 1); e2 = sload4(a.erec, ridx + 2);
+                                e3 = sload4(a.erec, ridx + 3);
+                            }
+                            if (COUNT) c.fetches += BUNDLE ? 4 : 8; // wave-uniform: 64-B record (+ 64-B eye record), in 16-B units
+                            act_ = alive;
+                        }
                         GRT_D(segments, 1)
-                        const uint32_t ridx = pidx * 4u;
-                        const float4 r0 = sload4(a.rec, ridx), r1 = sload4(a.rec, ridx + 1), r2 = sload4(a.rec, ridx + 2),
-                                     r3 = sload4(a.rec, ridx + 3);
-                        const float4 e0 = sload4(a.erec, ridx), e1 = sload4(a.erec, ridx + 1), e2 = sload4(a.erec, ridx + 2),
-                                     e3 = sload4(a.erec, ridx + 3);
-                        if (COUNT) c.fetches += 8; // wave-uniform: 64-B record + 64-B eye record, in 16-B units
+                        if (MODE == 1) work++;
                         const f3 mu = mk3(r0.x, r0.y, r0.z);
                         m33 A;
                         A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
                         A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
                         A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-                        const f3 o_g = mk3(e0.x, e0.y, e0.z); // A (o - mu), from the eye record (wave-uniform)
+                        // A (o - mu): from the eye record (wave-uniform), or per lane for a bundle
+                        const f3 o_g = BUNDLE ? matvec(A, sub3(o, mu)) : mk3(e0.x, e0.y, e0.z);
+                        const float cc_ = BUNDLE ? proxy_sphere_cc(o_g, r0.w) : e0.w;
                         const f3 d_g = matvec(A, d);
                         {   // conservative sphere pre-test (proxy_sphere_maybe_pre) as lane masks
                             const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
-                            const uint64_t m_ = (wave_ballot(e0.w <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * e0.w)) &
-                                                wave_ballot(alive);
+                            const uint64_t m_ = (wave_ballot(cc_ <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_)) &
+                                                wave_ballot(act_);
                             if (!m_) continue;
                         }
-                        if (COUNT && alive) c.proxy_tests++;
+                        if (COUNT && act_) c.proxy_tests++;
+                        if (MODE == 1) work += 2u;
                         GRT_D(proxy_tests, 1)
                         float te, tx;
-                        const float pa[10] = {e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y}; // slab_project(o_g)
-                        const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && alive;
+                        float pa[10]; // slab_project(o_g)
+                        if (BUNDLE) {
+                            slab_project(o_g, pa);
+                        } else {
+                            pa[0] = e1.x; pa[1] = e1.y; pa[2] = e1.z; pa[3] = e1.w; pa[4] = e2.x; pa[5] = e2.y; pa[6] = e2.z;
+                            pa[7] = e2.w; pa[8] = e3.x; pa[9] = e3.y;
+                        }
+                        const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && act_;
                         const uint32_t id = __float_as_uint(r2.w);
                         const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
                         // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
@@ -672,14 +847,14 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                             const bool drop = ins && full; // the farthest of (window + new particle) leaves the window
                             const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
                             if (wave_any(drop)) { // wave-uniform branch: into the lane's bag
-                                if (chunk == kNoRoot) { // first overflow of this tile: take a chunk of the pool
+                                if (!SINGLE && chunk == kNoRoot) { // first overflow of this tile: take a chunk of the pool
                                     uint32_t ch = 0;
                                     if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u);
                                     ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
                                     chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); // pool exhausted: drop for good
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = drop && (chunk < a.ovf_chunks) && (nb < kOvf);
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < kOvf);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
                                     a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
@@ -689,12 +864,23 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                                 }
                                 const bool gone = drop && !to_bag;
                                 lost = (gone && (dk < lost)) ? dk : lost;
-                                bags = true;
+                                if (SINGLE) lost = wave_umin64(lost); // one ray: one cut-off
+                                else bags = true;
                                 if (wave_any(gone)) lim_dirty = true;
                             }
                             KLAST = (take && full) ? kKeyInvalid : KLAST;
                             pmask = take ? (pmask | (1u << cell)) : pmask;
                             if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; }
+                            if (SINGLE && take) { // the event's radiance travels with it (fetched 64 at a time, not one per event)
+                                f3 L;
+                                if (!SH) {
+                                    const float4 cc = a.color0[id];
+                                    L = mk3(cc.x, cc.y, cc.z);
+                                } else {
+                                    L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max);
+                                }
+                                PL_COL(cell, 0) = L.x; PL_COL(cell, 1) = L.y; PL_COL(cell, 2) = L.z;
+                            }
                             SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid)
                         }
                     }
@@ -738,20 +924,39 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                 }
             }
             // a lane goes again only if it dropped something and still has transmittance left
+            if (aborted) break;
             const bool progressed = last_key != pass_lo;
-            stalls = progressed ? 0u : stalls + 1u;
+            stalls = parked ? stalls : (progressed ? 0u : stalls + 1u);
             const bool again = alive && (lost != kKeyInvalid);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
-            alive = again && (stalls < 2u) && !watchdog;
+            alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
-        if (a.cost && lane == 0) atomicMax(&a.cost[unit], iters);
+        if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[unit], iters);
     }
-    const float density = 1.0f - T;
+    if (MODE == 1 && aborted) { // wave-uniform: nothing is written, the chunk's rays join the heavy list
+        const uint64_t vm = wave_ballot(in_frame);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.hcount, (uint32_t)__popcll(vm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (in_frame) a.heavy[base + lanes_below(vm)] = (uint32_t)ent;
+        break;
+    }
+    // (no hittable particle: the density is left as it came, shaders/tracer.cuh:328-373 never runs)
+    const float density = (BUNDLE && a.root_ref == kNoRoot) ? density_in : 1.0f - T;
 
     f3 col = mk3(0.0f, 0.0f, 0.0f);
     bool cont = false; // MESH: the ray goes on bouncing (stage 3)
     f3 accumColor = mk3(0, 0, 0);
     float accumAlpha = 0.0f, blocking = 0.0f;
+    uint32_t timeout = 0;
+    if (BUNDLE && in_frame) { // the accumulators of the iterations before this one
+        const float4 q1 = a.queue_in[qi + 1], q2 = a.queue_in[qi + 2], q3 = a.queue_in[qi + 3];
+        accumColor = mk3(q1.z, q1.w, q2.x);
+        accumAlpha = q2.y;
+        blocking = q2.z;
+        timeout = __float_as_uint(q3.y) & 0x7FFFFFFFu;
+        col = accumColor;
+    }
     const uint32_t numBounces = (pflags >> 8) & 0xFFu;
     if (have_ray) {
         const float alpha = density;
@@ -777,27 +982,38 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
                     blocking = clampf(blocking + alpha, 0.0f, 1.0f);
                 }
                 accumColor = add3(accumColor, mul3s(directLight, 1.0f - blocking)); // shaders/tracer.cu:101
-                cont = (length3(nextD) > 0.1f) && (numBounces < a.p.max_bounces);
+                timeout += 1u;                                                      // shaders/tracer.cu:103-104
+                cont = (length3(nextD) > 0.1f) && (numBounces < a.p.max_bounces) && !(timeout > kTimeoutIterations);
             }
             col = accumColor;
         }
     }
     if (MESH) {
-        // ---- compaction of the rays that go on: wave ballot + popcount prefix + ONE atomic per wave ----
+        // ---- the rays that go on: the wave takes ONE 64-entry chunk of the queue (one atomic) and every lane writes
+        //      its own slot, so that stage 3 finds the rays of a tile together, as a bundle; bit 31 of the timeout word
+        //      marks the slots that carry a ray ----
         const uint64_t mask = wave_ballot(cont);
-        if (mask) { // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.qcount, (uint32_t)__popcll(mask));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (cont) {
-                const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                float4* q = a.queue + (size_t)slot * 4;
+        if (SINGLE) { // a lone ray: one slot of the packed queue that only the per-lane kernel reads
+            if (cont && lane == 0u) {
+                float4* q = a.fqueue + (size_t)atomicAdd(a.fcount, 1u) * 4;
                 q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
                 q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);
                 q[2] = make_float4(accumColor.z, accumAlpha, blocking, density);
-                q[3] = make_float4(__uint_as_float(numBounces), __uint_as_float(1u), // timeout after one iteration
+                q[3] = make_float4(__uint_as_float(numBounces), __uint_as_float(timeout | 0x80000000u),
                                    __uint_as_float((uint32_t)out_idx), __uint_as_float((uint32_t)(out_idx >> 32)));
             }
+        } else if (mask) { // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.qcount, 1u);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            float4* q = a.queue + ((size_t)base * 64u + lane) * 4;
+            if (cont) {
+                q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
+                q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);
+                q[2] = make_float4(accumColor.z, accumAlpha, blocking, density);
+            }
+            q[3] = make_float4(__uint_as_float(numBounces), __uint_as_float(timeout | (cont ? 0x80000000u : 0u)),
+                               __uint_as_float((uint32_t)out_idx), __uint_as_float((uint32_t)(out_idx >> 32)));
         }
     }
     const bool write_px = write && !cont; // queued rays write their pixel in stage 3
@@ -834,6 +1050,8 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
         }
         if (c.stall_exits) atomicAdd(&a.counters[7], (unsigned long long)c.stall_exits);
     }
+    if (!SINGLE) break;
+    } // for unit_s
 }
 
 #undef KS
@@ -841,30 +1059,39 @@ __global__ __launch_bounds__(kWG, GRT_TILE_WAVES) void k_render_tile(const Rende
 #undef KPRESS
 #undef PL_OTHER
 #undef PL_ALPHA
+#undef PL_COL
 
 } // namespace
 
 typedef void (*TileKernel)(const RenderArgs);
-static TileKernel pick_tile(bool count, bool sh, bool mesh)
+static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode)
 {
-#define GRT_PICK(K)                                                                                        \
-    (count ? (sh ? (mesh ? K<true, true, true> : K<true, true, false>) : (mesh ? K<true, false, true> : K<true, false, false>)) \
-           : (sh ? (mesh ? K<false, true, true> : K<false, true, false>) : (mesh ? K<false, false, true> : K<false, false, false>)))
-    return GRT_PICK(k_render_tile);
-#undef GRT_PICK
+#define GRT_PICK2(C, S)                                                                                    \
+    (mode == 2 ? k_render_tile<C, S, true, 2> : (mode == 1 ? k_render_tile<C, S, true, 1>                  \
+               : (mesh ? k_render_tile<C, S, true, 0> : k_render_tile<C, S, false, 0>)))
+    return count ? (sh ? GRT_PICK2(true, true) : GRT_PICK2(true, false)) : (sh ? GRT_PICK2(false, true) : GRT_PICK2(false, false));
+#undef GRT_PICK2
 }
 
-int launch_render_tile(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, std::string* err)
+// mode 0: camera rays (mesh = stage 2 of the wavefront pipeline: up to their mesh hit); mode 1: stage 3, one wave per
+// chunk of a.queue_in (grid = the most chunks there can be: one per 8x8 tile of the launch); mode 2: one wave per ray of
+// the heavy list, a resident grid striding over it
+int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
-    if (a.root_ref != kNoRoot && (!a.pbox || (!(a.root_ref & kLeafBit) && !a.qnodes) || !a.erec)) {
+    if (a.root_ref != kNoRoot && (!a.pbox || (!(a.root_ref & kLeafBit) && !a.qnodes) || (mode == 0 && !a.erec))) {
         if (err) *err = "tile kernel: per-child BVH layout or eye records missing";
+        return GRT_ERR_INVALID;
+    }
+    if (mode != 0 && (!a.queue_in || !a.qcount_in || !a.prec || !a.queue || !a.qcount || !a.heavy || !a.hcount || !a.fqueue || !a.fcount)) {
+        if (err) *err = "tile kernel: continuation queues missing";
         return GRT_ERR_INVALID;
     }
     const bool sh = a.p.sh_degree_max > 0;
     RenderArgs b = a;
     b.heavy_role = 0;
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh), dim3(a.n_blocks * 4u), dim3(kWG), 0, stream, b);
+    const uint32_t grid = (mode == 2) ? 2048u : a.n_blocks * 4u; // mode 2: 8 waves per CU are resident (19 KB of LDS each)
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode), dim3(grid), dim3(kWG), 0, stream, b);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("k_render_tile launch: ") + hipGetErrorString(e);

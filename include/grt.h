@@ -144,7 +144,15 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_SIZE_CLASSES = 14      /* 1 (default): proxies much larger than average get subtrees of their own in the Gaussian LBVH
                                          (size class in the top Morton bits); 0: plain Morton order.  Process-wide; next build */,
        GRT_OPT_COLD_ESTIMATE = 15     /* 1 (default): a frame with no previous-frame costs (first frame, new size) launches its tiles in the
-                                         order of the number of particle centres projecting into them; 0: screen order */ };
+                                         order of the number of particle centres projecting into them; 0: screen order */,
+       GRT_OPT_BUNDLE_ROUNDS = 16     /* mesh frames on the tile kernel: how many bounce iterations trace their Gaussian segment wave-
+                                         cooperatively (the bounced rays of an 8x8 tile as one bundle) before the per-lane kernel
+                                         finishes whatever still bounces; 0..4, default 2.  Same image for every value */,
+       GRT_OPT_BUNDLE_BUDGET = 17     /* work (steps + particles fetched + 2 x exact tests) a bundle may take before it is given up and its
+                                         rays are traced one per wave (a bundle whose rays have spread too far to share work); default
+                                         1024.  Same image for every value */,
+       GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 1024 = 100 %) */,
+       GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

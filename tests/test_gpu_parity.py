@@ -420,3 +420,47 @@ def test_moved_mesh_refit_matches_rebuild_and_oracle(tr):
     with pytest.raises(grt.GrtError, match="counts differ"):
         tr.update_meshes([(v2, n2, f2)])
     tr.set_meshes([])
+
+
+@pytest.mark.parametrize("mesh_type", [grt.MIRROR, grt.GLASS])
+def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type):
+    """Mesh frames on the tile kernel: the bounced rays go through k_queue_mesh + the bundle kernel (a wave per 8x8
+    tile's rays), chunks over budget through the one-ray-per-wave mode, whatever still bounces after the bundle rounds
+    through the per-lane kernel.  Every split of the work between the three must give the per-lane megakernel's frame
+    bit for bit, and the oracle's within tolerance: 0 rounds (per-lane only), budget 1 (every ray alone on a wave),
+    default, 4 rounds with a small budget (lone rays that keep bouncing -> the packed queue)."""
+    acts, p, sc, op, center = make_scene(51, 20000, 192, 160, scale_boost=0.7, mesh_type=mesh_type, max_bounces=8)
+    eye = np.float32([0, 0, 3])
+    base = (0.25 * center + 0.75 * eye).astype(np.float32)
+    v1, n1, f1 = grt.sphere_mesh(base + np.float32([0.25, 0, 0]), tess_u=48, tess_v=24)
+    v2, n2, f2 = grt.sphere_mesh(base - np.float32([0.45, 0.1, 0.2]), tess_u=32, tess_v=16)
+    meshes = [(v1, n1, f1), (v2, n2, f2)]
+    ref_t = grt.Tracer(0)
+    ref_t.set_option(grt.OPT_KERNEL, 1)
+    ref_t.upload(acts)
+    ref_t.set_meshes(meshes)
+    ref_u8, ref_f32 = ref_t.render(p, want_f32=True)
+    ref_t.close()
+    t = grt.Tracer(0)
+    t.upload(acts)
+    t.set_meshes(meshes)
+    t.set_option(grt.OPT_COUNTERS, 1)
+    routes = {"per-lane only": (0, 1024), "all alone": (2, 1), "default": (2, 1024), "deep": (4, 24), "one round": (1, 64)}
+    segs = set()
+    for name, (rounds, budget) in routes.items():
+        t.set_option(grt.OPT_BUNDLE_ROUNDS, rounds)
+        t.set_option(grt.OPT_BUNDLE_BUDGET, budget)
+        u8, f32 = t.render(p, want_f32=True)
+        cnt = t.counters()
+        assert bool((u8 == ref_u8).all()), name
+        assert bool((f32 == ref_f32).all()), name
+        assert cnt["stall_exits"] == 0, name
+        segs.add((cnt["segments"], cnt["hit_evals"]))
+    assert len(segs) == 1  # the same segments and the same composited events on every route
+    with pytest.raises(grt.GrtError):
+        t.set_option(grt.OPT_BUNDLE_ROUNDS, 5)
+    t.close()
+    sc.set_mesh(np.concatenate([v1, v2]), np.concatenate([n1, n2]), np.concatenate([f1, f2 + len(v1)]))
+    o_u8, o_f32, rc = sc.render(op)
+    compare(ref_f32, o_f32, ref_u8, o_u8)
+    assert next(iter(segs))[0] == rc["segments"] and rc["segments"] > 1.2 * rc["rays"]
