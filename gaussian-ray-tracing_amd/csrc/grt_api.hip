@@ -762,9 +762,11 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.tile_prio_div = (uint32_t)c->opt_tile_prio;
     a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
     if (tile_kernel) {
-        // pool of window-overflow bags: a chunk (kTileOvfChunkBytes) per tile that overflows; sized for a quarter of the
-        // tiles (a tile that finds the pool empty falls back to another pass — slower, never wrong)
-        const uint32_t want = std::max(256u, a.n_blocks);
+        // pool of window-overflow bags: a chunk (kTileOvfChunkBytes = 96 KiB) per tile that overflows, and one for EVERY
+        // tile of the launch (3.1 GB for a 1080p frame; only the chunks that are taken are ever touched): a tile that
+        // finds the pool empty falls back to another pass — never wrong, but on the default 1 M scene a pool for a
+        // quarter of the tiles ran dry and cost the frame 12 %
+        const uint32_t want = std::max(256u, a.n_blocks * 4u);
         if (c->ovf_chunks < want) {
             (void)hipFree(c->d_ovf);
             c->d_ovf = nullptr;

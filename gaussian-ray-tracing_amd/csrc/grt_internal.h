@@ -147,7 +147,10 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
 // round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the packed queue of lone rays
 constexpr int kWfCounters = 2 * kMaxBundleRounds + 2;
-constexpr uint32_t kTileOvfEntries = 96; // GRT_TILE_OVF of grt_render_tile.hip
+#ifndef GRT_TILE_OVF
+#define GRT_TILE_OVF 96
+#endif
+constexpr uint32_t kTileOvfEntries = GRT_TILE_OVF; // per-lane capacity of a window-overflow bag
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
 // GRT_OPT_KERNEL values: 0 auto (tile kernel where it applies, else streaming), 1 per-lane, 2 round-based wave,
 // 3 streaming, 4 big-window streaming (testing), 5 tile
