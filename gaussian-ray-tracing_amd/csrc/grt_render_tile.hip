@@ -56,6 +56,9 @@ constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's 
 #ifndef GRT_BISECT
 #define GRT_BISECT 18 /* most bisection steps of a nearest-k selection (4 / 6 at least) */
 #endif
+#ifndef GRT_RF_ROOM
+#define GRT_RF_ROOM k8 /* a lane with room above this slot joins a refill scan it does not need yet */
+#endif
 #define GRT_KS 12
 #define KS 12
 #define KLAST k11
@@ -131,6 +134,62 @@ __device__ __forceinline__ void wave_fence()
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // compiler ordering of the LDS exchange; no instruction
 #endif
+}
+
+// A full overflow bag keeps its nearer half.  Without this the key that no longer fits is simply dropped, and that key is
+// the window's own last one: the lane's cut-off then sits a dozen events ahead however much the bag holds, and a ray inside
+// hundreds of overlapping proxies (all their exit events pending at once) needs a pass per dozen events.  Pruning instead
+// keeps the cut-off at about the bag's median, ~50 events ahead, and costs seven scans of the bag a few times per tile.
+// Lanes with `doit` prune; bp = the lane's column of its tile's chunk (entry i at bp[i * 64]).  Called between steps
+// (few values live there), as soon as a bag is two thirds full: a leaf step rarely adds more than 32 events to a lane.
+__device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, uint64_t& bagmin, uint64_t& lost)
+{
+    const uint32_t n = doit ? nb : 0u;
+    uint32_t nmax = n;
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u; // bit patterns of the keys' t (positive floats order like integers)
+    for (uint32_t i = 0; i < nmax; i++) {
+        if (i < n) {
+            const uint32_t t = __float_as_uint(bp[(size_t)i * 64u].y);
+            lo = min(lo, t);
+            hi = max(hi, t);
+        }
+    }
+    uint32_t cnt_lo = 0; // entries with t <= lo (unknown yet: at least one)
+    for (int it = 0; it < 5; it++) { // the largest threshold that keeps at most half of the entries
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t cnt = 0;
+        for (uint32_t i = 0; i < nmax; i++)
+            if (i < n) cnt += (__float_as_uint(bp[(size_t)i * 64u].y) <= mid) ? 1u : 0u;
+        const bool few = cnt * 2u <= n;
+        cnt_lo = few ? cnt : cnt_lo;
+        lo = few ? mid : lo;
+        hi = few ? hi : mid;
+    }
+    // entries with t <= lo stay; when that is none or all of them (equal distances), the first half by position stays
+    const bool by_pos = (cnt_lo == 0u) || (cnt_lo >= n);
+    uint32_t w = 0;
+    uint64_t newmin = kKeyInvalid, dropmin = kKeyInvalid;
+    for (uint32_t i = 0; i < nmax; i++) {
+        if (i < n) {
+            const float4 e = bp[(size_t)i * 64u];
+            const uint64_t key = ((uint64_t)__float_as_uint(e.y) << 32) | (uint64_t)__float_as_uint(e.x);
+            const bool keep = by_pos ? (i < (n >> 1)) : (__float_as_uint(e.y) <= lo);
+            if (keep) {
+                bp[(size_t)w * 64u] = e;
+                newmin = (key < newmin) ? key : newmin;
+                w++;
+            } else {
+                dropmin = (key < dropmin) ? key : dropmin;
+            }
+        }
+    }
+    if (doit) {
+        nb = w;
+        bagmin = newmin;
+        lost = (dropmin < lost) ? dropmin : lost;
+    }
 }
 
 // BUNDLE = true (stage 3 of the mesh wavefront pipeline): the wave's 64 rays are one chunk of the continuation queue —
@@ -495,6 +554,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
 
                 // ---- composite buffered events with t < F (and key < cutoff), in key order; deferred until
                 //      ready_min lanes have one, a window is nearly full, or the pass is over ----
+                if (!SINGLE && !dfs && bags) {
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb >= kOvf - 32u);
+                    if (wave_any(pr_)) { // wave-uniform, rare
+                        bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
+                        lim_dirty = true;
+                    }
+                }
                 if (SINGLE && !dfs) {
                     // ---- MODE 2: the pool's smallest final key, one event per trip; T / radiance are wave-uniform ----
                     while (true) {
@@ -549,7 +615,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                             GRT_D(node_visits, 1)
                             // lanes that do not need it yet but have room for four more keys come along: one scan instead
                             // of one per lane a few steps apart
-                            const bool rf = need || (alive && (nb != 0u) && (k8 == kKeyInvalid) && (bagmin < lost));
+                            const bool rf = need || (alive && (nb != 0u) && (GRT_RF_ROOM == kKeyInvalid) && (bagmin < lost));
                             uint32_t nmax = rf ? nb : 0u;
                             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
                             nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
@@ -854,7 +920,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                                     chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); // pool exhausted: drop for good
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < kOvf);
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < kOvf) && (dk < lost);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
                                     a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =

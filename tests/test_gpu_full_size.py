@@ -150,7 +150,7 @@ def test_c4_full_size_mirror_sphere_through_the_obj_path(tmp_path):
 def test_anisotropic_scene_crowded_frontier_kernel_independence():
     """Needle / pancake Gaussians at scale (per-axis log-scale noise sigma 1.2 on 300 k Gaussians): proxies that span a
     large part of the scene overlap by the hundred, the tile kernel's frontier spills to its LDS bag and is rebalanced
-    over and over, windows overflow into the per-lane bags, lanes take several passes.  The tile kernel (default), the
+    over and over, windows overflow into the per-lane bags, full bags are pruned, some lanes take another pass.  The tile kernel (default), the
     streaming kernel and the round-based kernel must still agree bit for bit, with and without the size classes of the
     LBVH, and the oracle agrees on sampled windows."""
     W, H = 960, 540
@@ -174,7 +174,8 @@ def test_anisotropic_scene_crowded_frontier_kernel_independence():
         tr.set_option(grt.OPT_SIZE_CLASSES, 1)
         tr.close()
     u8, f32, cnt = frames[(0, 1)]
-    assert cnt["rounds"] > 1.2 * cnt["rays"]  # windows overflow for good: lanes go again
+    # windows overflow, full bags are pruned to their nearer half, and some lanes still go again
+    assert cnt["rounds"] > cnt["rays"] + 500
     for key, (a8, af, c2) in frames.items():
         assert (a8 == u8).all() and (af == f32).all(), key
         assert c2["hit_evals"] == cnt["hit_evals"], key
