@@ -63,7 +63,7 @@ def kernel_name(variant, with_mesh, sh_degree, leaf_max=4):
     if variant == 2 and not with_mesh:
         return f"grt::k_render_wave<false, {sh}>"
     if variant in (0, 5) and leaf_max <= 4:
-        return f"grt::k_render_tile<false, {sh}, {mesh}>"
+        return f"grt::k_render_tile<false, {sh}, {mesh}, 0>"
     return f"grt::k_render_stream<false, {sh}, {mesh}>"
 
 

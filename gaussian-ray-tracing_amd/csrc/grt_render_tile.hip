@@ -56,6 +56,9 @@ constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's 
 #ifndef GRT_BISECT
 #define GRT_BISECT 18 /* most bisection steps of a nearest-k selection (4 / 6 at least) */
 #endif
+#ifndef GRT_PRUNE_ROOM
+#define GRT_PRUNE_ROOM 32u /* a bag with less room than this is pruned between steps */
+#endif
 #ifndef GRT_RF_ROOM
 #define GRT_RF_ROOM k8 /* a lane with room above this slot joins a refill scan it does not need yet */
 #endif
@@ -139,44 +142,42 @@ __device__ __forceinline__ void wave_fence()
 // A full overflow bag keeps its nearer half.  Without this the key that no longer fits is simply dropped, and that key is
 // the window's own last one: the lane's cut-off then sits a dozen events ahead however much the bag holds, and a ray inside
 // hundreds of overlapping proxies (all their exit events pending at once) needs a pass per dozen events.  Pruning instead
-// keeps the cut-off at about the bag's median, ~50 events ahead, and costs seven scans of the bag a few times per tile.
+// keeps the cut-off at about the bag's median, ~50 events ahead, for one scan of the bag (+ five of a 16-entry sample).
 // Lanes with `doit` prune; bp = the lane's column of its tile's chunk (entry i at bp[i * 64]).  Called between steps
-// (few values live there), as soon as a bag is two thirds full: a leaf step rarely adds more than 32 events to a lane.
+// (few values live there), as soon as a bag has fewer than GRT_PRUNE_ROOM free entries.
 __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, uint64_t& bagmin, uint64_t& lost)
 {
     const uint32_t n = doit ? nb : 0u;
     uint32_t nmax = n;
     for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    // the threshold comes from a SAMPLE: the first 16 entries (the bag is in arrival order, which does not know the keys)
+    const uint32_t ns = min(n, 16u), nsmax = min(nmax, 16u);
     uint32_t lo = 0xFFFFFFFFu, hi = 0u; // bit patterns of the keys' t (positive floats order like integers)
-    for (uint32_t i = 0; i < nmax; i++) {
-        if (i < n) {
+    for (uint32_t i = 0; i < nsmax; i++) {
+        if (i < ns) {
             const uint32_t t = __float_as_uint(bp[(size_t)i * 64u].y);
             lo = min(lo, t);
             hi = max(hi, t);
         }
     }
-    uint32_t cnt_lo = 0; // entries with t <= lo (unknown yet: at least one)
-    for (int it = 0; it < 5; it++) { // the largest threshold that keeps at most half of the entries
+    for (int it = 0; it < 4; it++) { // the largest threshold (to 1/16 of the range) that keeps at most half of the sample
         const uint32_t mid = lo + ((hi - lo) >> 1);
         uint32_t cnt = 0;
-        for (uint32_t i = 0; i < nmax; i++)
-            if (i < n) cnt += (__float_as_uint(bp[(size_t)i * 64u].y) <= mid) ? 1u : 0u;
-        const bool few = cnt * 2u <= n;
-        cnt_lo = few ? cnt : cnt_lo;
+        for (uint32_t i = 0; i < nsmax; i++)
+            if (i < ns) cnt += (__float_as_uint(bp[(size_t)i * 64u].y) <= mid) ? 1u : 0u;
+        const bool few = cnt * 2u <= ns;
         lo = few ? mid : lo;
         hi = few ? hi : mid;
     }
-    // entries with t <= lo stay; when that is none or all of them (equal distances), the first half by position stays
-    const bool by_pos = (cnt_lo == 0u) || (cnt_lo >= n);
+    // entries with t <= lo stay
     uint32_t w = 0;
     uint64_t newmin = kKeyInvalid, dropmin = kKeyInvalid;
     for (uint32_t i = 0; i < nmax; i++) {
         if (i < n) {
             const float4 e = bp[(size_t)i * 64u];
             const uint64_t key = ((uint64_t)__float_as_uint(e.y) << 32) | (uint64_t)__float_as_uint(e.x);
-            const bool keep = by_pos ? (i < (n >> 1)) : (__float_as_uint(e.y) <= lo);
-            if (keep) {
+            if (__float_as_uint(e.y) <= lo) {
                 bp[(size_t)w * 64u] = e;
                 newmin = (key < newmin) ? key : newmin;
                 w++;
@@ -184,6 +185,19 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
                 dropmin = (key < dropmin) ? key : dropmin;
             }
         }
+    }
+    // (equal distances, or a sample that misled: the bag must shrink whatever happens — the last quarter goes)
+    const bool trunc = doit && (w * 8u > n * 7u);
+    if (wave_any(trunc)) {
+        const uint32_t w2 = trunc ? (w - (w >> 2)) : w;
+        for (uint32_t i = 0; i < nmax; i++) {
+            if (trunc && i >= w2 && i < w) {
+                const float4 e = bp[(size_t)i * 64u];
+                const uint64_t key = ((uint64_t)__float_as_uint(e.y) << 32) | (uint64_t)__float_as_uint(e.x);
+                dropmin = (key < dropmin) ? key : dropmin;
+            }
+        }
+        w = w2; // (newmin may now name a dropped entry: a smaller bagmin only asks for a refill early)
     }
     if (doit) {
         nb = w;
@@ -394,7 +408,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
         // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
         const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;
 
+        uint32_t npass = 0;
         while (wave_any(alive)) { // one iteration = one front-to-back pass
+            npass++;
             bool parked = false; // BUNDLE: alive, but outside this pass's cone of directions
             if (BUNDLE) {
                 GRT_AXES(wave_ballot(alive))
@@ -554,8 +570,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
 
                 // ---- composite buffered events with t < F (and key < cutoff), in key order; deferred until
                 //      ready_min lanes have one, a window is nearly full, or the pass is over ----
-                if (!SINGLE && !dfs && bags) {
-                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb >= kOvf - 32u);
+                // A bag is pruned only where an overflow would hurt: while the front still stands at the start of the pass
+                // (the particles that CONTAIN the origin arrive in no order at all, by the hundred in a dense cluster), and in
+                // any later pass (a lane came back: its cut-off did fall short).  Behind a moving front the arrivals are
+                // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
+                if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb >= kOvf - GRT_PRUNE_ROOM);
                     if (wave_any(pr_)) { // wave-uniform, rare
                         bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
                         lim_dirty = true;

@@ -6,7 +6,7 @@ import csv, datetime, glob, json, os, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
-KERNEL = "k_render_tile<false, false, false>"
+KERNEL = "k_render_tile<false, false, false, 0>"
 
 for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.reader(open(f)))
