@@ -464,3 +464,38 @@ def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type):
     o_u8, o_f32, rc = sc.render(op)
     compare(ref_f32, o_f32, ref_u8, o_u8)
     assert next(iter(segs))[0] == rc["segments"] and rc["segments"] > 1.2 * rc["rays"]
+
+
+def test_camera_inside_a_dense_cluster_full_bags_are_pruned():
+    """The eye sits in the densest cell of the scene, inside hundreds of overlapping proxies: their exit events are all
+    pending at once and arrive in no order, every lane's window overflows into its bag, full bags keep their nearer half
+    (grt_render_tile.hip: bag_prune) and some lanes still go again.  Tile kernel == streaming kernel == per-lane kernel
+    bit for bit, and the oracle within tolerance."""
+    W, H = 160, 128
+    acts, p0, sc, op0, center = make_scene(61, 60000, W, H, scale_boost=1.3)
+    pos = acts["pos"]
+    h, edges = np.histogramdd(pos, bins=24, range=[(-1.5, 1.5)] * 3)
+    i = np.unravel_index(np.argmax(h), h.shape)
+    eye = tuple(float((edges[k][i[k]] + edges[k][i[k] + 1]) / 2) for k in range(3))
+    p = grt.default_params(W, H, center, eye=eye)
+    frames = {}
+    for kernel in (0, 3, 1):
+        t = grt.Tracer(0)
+        t.set_option(grt.OPT_KERNEL, kernel)
+        t.upload(acts)
+        t.set_option(grt.OPT_COUNTERS, 1)
+        u8, f32 = t.render(p, want_f32=True)
+        frames[kernel] = (u8.clone(), f32.clone(), t.counters())
+        t.close()
+    u8, f32, cnt = frames[0]
+    assert cnt["stall_exits"] == 0
+    assert cnt["proxy_tests"] > 300 * cnt["rays"]        # hundreds of proxies around the eye
+    assert cnt["rounds"] > cnt["rays"]                   # some lanes went again ...
+    assert cnt["rounds"] < 2.5 * cnt["rays"]             # ... but not a pass per dozen events (3.9 before the pruning)
+    for k in (3, 1):
+        assert bool((frames[k][0] == u8).all()) and bool((frames[k][1] == f32).all()), k
+        assert frames[k][2]["hit_evals"] == cnt["hit_evals"], k
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p), threads=8)
+    compare(f32, ref_f32, u8, ref_u8)
+    assert rc["hit_evals"] == cnt["hit_evals"]
+    sc.close()
