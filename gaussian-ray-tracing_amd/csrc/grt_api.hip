@@ -317,6 +317,7 @@ const char* grt_last_error(const grt_ctx* c) { return c ? c->err.c_str() : g_cre
 int grt_set_option(grt_ctx* c, int option, int value)
 {
     if (!c) return GRT_ERR_INVALID;
+    c->order_ready = false; // prepared with the old options
     if (option == GRT_OPT_COUNTERS) c->opt_counters = value ? 1 : 0;
     else if (option == GRT_OPT_KERNEL) {
         if (value < 0 || value > GRT_KERNEL_MAX) { c->err = "GRT_OPT_KERNEL must be 0.." + std::to_string(GRT_KERNEL_MAX); return GRT_ERR_INVALID; }
@@ -624,6 +625,21 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // launch.  Pure scheduling: pixels do not depend on the order.  A viewer's consecutive frames are nearly identical,
 // which is what makes last frame's cost a good predictor; the first frame (or any change of size / mode) runs in
 // the default XCD-chunked order.
+// launch order of the units from the costs the last frame left in d_cost (dilated for full-frame launches)
+static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, hipStream_t s, bool* used_split)
+{
+    const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
+    const uint32_t* cost_src = c->d_cost;
+    if (c->opt_cost_radius > 0 && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
+        int rcd = dilate_unit_costs(c->d_cost, c->d_cost_dil, a.nbx, a.nby, c->opt_cost_radius, s, &c->err);
+        if (rcd != GRT_OK) return rcd;
+        cost_src = c->d_cost_dil;
+    }
+    *used_split = split;
+    return order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
+                               (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
+}
+
 static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units)
 {
     a.order = nullptr;
@@ -647,18 +663,14 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     if (same) {
-        const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
-        const uint32_t* cost_src = c->d_cost;
-        if (c->opt_cost_radius > 0 && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
-            int rcd = dilate_unit_costs(c->d_cost, c->d_cost_dil, a.nbx, a.nby, c->opt_cost_radius, s, &c->err);
-            if (rcd != GRT_OK) return rcd;
-            cost_src = c->d_cost_dil;
+        // (normally already there: do_launch orders the units for the next frame right behind this frame's kernels,
+        //  where it fills the gap between two frames instead of delaying the next one)
+        if (!c->order_ready) {
+            int rc = order_from_costs(c, a, n_units, s, &c->order_split);
+            if (rc != GRT_OK) return rc;
         }
-        int rc = order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
-                                     (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
-        if (rc != GRT_OK) return rc;
         a.order = c->d_order;
-        if (split) a.n_heavy = c->d_n_heavy;
+        if (c->order_split) a.n_heavy = c->d_n_heavy;
     } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && c->n && (a.mode == 0 || a.mode == 1)) {
         // no costs of a previous frame with this geometry: order the tiles by the number of particle centres that
         // project into them (dense tiles first), so that the first frame's long tiles do not start last
@@ -676,10 +688,12 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
     }
-    CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
+    if (!(same && c->cost_zeroed)) CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
     a.cost = c->d_cost;
     memcpy(c->cost_sig, sig, sizeof(sig));
     c->cost_valid = true;
+    c->order_ready = false;
+    c->cost_zeroed = false;
     return GRT_OK;
 }
 
@@ -775,12 +789,21 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
             c->ovf_chunks = want;
         }
         if (!c->d_ovf_next) CHK(c, hipMalloc(&c->d_ovf_next, sizeof(uint32_t)));
-        CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
+        if (!c->ovf_zeroed) CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
+        c->ovf_zeroed = false;
         a.ovf_pool = c->d_ovf; a.ovf_next = c->d_ovf_next; a.ovf_chunks = c->ovf_chunks;
     }
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);
+    if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order, behind this frame (not in its timing)
+        if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
+            c->order_ready = true;
+            // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)
+            if (hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_units, s) == hipSuccess) c->cost_zeroed = true;
+        }
+    }
+    if (rc == GRT_OK && a.ovf_next && hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s) == hipSuccess) c->ovf_zeroed = true;
     return rc;
 }
 

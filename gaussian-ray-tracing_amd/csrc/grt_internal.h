@@ -225,6 +225,9 @@ struct grt_ctx {
     int opt_cold_estimate = 1; // order a frame without previous-frame costs by projected particle counts
     uint32_t cost_cap = 0;
     bool cost_valid = false;
+    bool order_ready = false; // d_order already holds the order for the next frame with this geometry (do_launch, post-frame)
+    bool order_split = false;
+    bool cost_zeroed = false, ovf_zeroed = false; // d_cost / d_ovf_next were zeroed behind the last frame
     // wavefront buffers (allocated on first mesh frame)
     float4 *d_prec = nullptr, *d_queue = nullptr; // d_queue: two queues (ping-pong between the stages)
     uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)
