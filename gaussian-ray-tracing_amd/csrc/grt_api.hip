@@ -713,7 +713,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
     a.prec = nullptr; a.queue = nullptr; a.qcount = nullptr;
     a.queue_in = nullptr; a.qcount_in = nullptr; a.queue_alt = nullptr;
-    a.heavy = nullptr; a.hcount = nullptr; a.fqueue = nullptr; a.fcount = nullptr; a.queue_in_packed = 0;
+    a.heavy = nullptr; a.hcount = nullptr; a.hnext = nullptr; a.fqueue = nullptr; a.fcount = nullptr; a.queue_in_packed = 0;
     a.bundle_rounds = (uint32_t)c->opt_bundle_rounds;
     a.bundle_budget = (uint32_t)c->opt_bundle_budget;
     a.single_look = (float)c->opt_single_look / 1024.0f;

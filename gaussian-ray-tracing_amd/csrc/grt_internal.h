@@ -123,6 +123,7 @@ struct RenderArgs {
     uint32_t bundle_budget;   // steps a chunk may take on the bundle kernel before its rays are traced one per wave
     uint32_t* heavy;          // [n_blocks*256] entries of queue_in whose chunk gave up (written by mode 1, read by mode 2)
     uint32_t* hcount;
+    uint32_t* hnext;          // mode 2: next entry of the heavy list to be drawn (zeroed with the other counters)
     float4* fqueue;           // [n_blocks*256][4] PACKED queue of the lone rays that go on (read by k_bounce only)
     uint32_t* fcount;
     uint32_t queue_in_packed; // k_bounce: *qcount_in counts entries, not 64-entry chunks
@@ -145,8 +146,9 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
 constexpr int kNumCounters = 8;
 constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
-// round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the packed queue of lone rays
-constexpr int kWfCounters = 2 * kMaxBundleRounds + 2;
+// round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the packed queue of lone rays,
+// [2R+2 .. 3R+1] the draw counter of round r's one-ray-per-wave launch
+constexpr int kWfCounters = 3 * kMaxBundleRounds + 2;
 #ifndef GRT_TILE_OVF
 #define GRT_TILE_OVF 96
 #endif

@@ -623,6 +623,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
             b.queue = q[in ^ 1u]; b.qcount = a.qcount + stage + 1u;
             b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
+            b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
             hipLaunchKernelGGL(fq, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
             rc = launch_render_tile(b, count, true, 1, stream, err);
             if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err);

@@ -213,7 +213,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // so that the bundle's frustum stays a useful cull.  The per-eye records do not apply: A (o - mu) is formed per lane.
 // A bundle that is not one — rays spread wide AND through dense parts of the scene — makes every step pay for 64 rays that
 // share nothing.  MODE 1 therefore works to a budget of steps: a chunk that exceeds it gives up, nothing of it is kept, and
-// its rays go on the `heavy` list; MODE 2 traces the rays of that list ONE PER WAVE, a fixed grid striding over the list.
+// its rays go on the `heavy` list; MODE 2 traces the rays of that list ONE PER WAVE, a resident grid drawing from the list.
 // There every lane holds the same ray, and the exact work turns round as well: LANES = PARTICLES.  The (<= 64) particles
 // of a leaf step are slab-tested at once, each by the lane that culled its box (record by vector loads); a hit goes into
 // THAT lane's window together with its colour, so the 64 windows are one pool of 768 pending events; compositing takes
@@ -235,7 +235,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
     __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + 3 siblings per level
                                  // below it (<= 3 * 62 for the tree heights the launcher sends here)
-    for (uint32_t unit_s = rank;; unit_s += gridDim.x) { // (one trip; MODE 2: a stride over the heavy list)
+    for (uint32_t unit_s = rank;;) { // (one trip; MODE 2: the waves draw the rays of the heavy list from a counter, so
+                                     //  that a wave stuck with a long ray does not hold a share of the others back)
+    if (SINGLE) {
+        uint32_t u_ = 0;
+        if (lane == 0u) u_ = atomicAdd(a.hnext, 1u);
+        unit_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_);
+    }
     if (BUNDLE && unit_s >= n_in) break; // wave-uniform
     Cnt c, w;
     (void)w;
@@ -1169,7 +1175,7 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
         if (err) *err = "tile kernel: per-child BVH layout or eye records missing";
         return GRT_ERR_INVALID;
     }
-    if (mode != 0 && (!a.queue_in || !a.qcount_in || !a.prec || !a.queue || !a.qcount || !a.heavy || !a.hcount || !a.fqueue || !a.fcount)) {
+    if (mode != 0 && (!a.queue_in || !a.qcount_in || !a.prec || !a.queue || !a.qcount || !a.heavy || !a.hcount || !a.fqueue || !a.fcount || !a.hnext)) {
         if (err) *err = "tile kernel: continuation queues missing";
         return GRT_ERR_INVALID;
     }
