@@ -147,6 +147,43 @@ def test_c4_full_size_mirror_sphere_through_the_obj_path(tmp_path):
     sc.close()
 
 
+def test_c4_scale_glass_sphere_deep_bounces_pipeline_independence():
+    """The 1 M scene at 1920x1080 with a GLASS sphere and up to 6 bounces (rays refract into the sphere, reflect inside,
+    leave again): bundle rounds, chunks over budget, lone rays on the packed queue and the per-lane finish all carry
+    rays here.  The default pipeline, the pipeline with 4 bundle rounds and a small budget, the streaming-kernel
+    pipeline (per-lane bounces only) and, on a window, the per-lane megakernel agree bit for bit."""
+    W, H = 1920, 1080
+    acts, p, sc, op, center = make_scene(3, 1_000_000, W, H, mesh_type=grt.GLASS, max_bounces=6)
+    sc.close()
+    pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+    v, n, f = grt.sphere_mesh(pos, tess_u=64, tess_v=32)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_meshes([(v, n, f)])
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    u8, f32 = u8.clone(), f32.clone()
+    assert cnt["segments"] > 1.5 * cnt["rays"] and cnt["stall_exits"] == 0  # several segments per sphere pixel
+    tr.set_option(grt.OPT_BUNDLE_ROUNDS, 4)
+    tr.set_option(grt.OPT_BUNDLE_BUDGET, 96)
+    a8, af = tr.render(p, want_f32=True)
+    c2 = tr.counters()
+    assert (a8 == u8).all() and (af == f32).all()
+    assert c2["segments"] == cnt["segments"] and c2["hit_evals"] == cnt["hit_evals"] and c2["stall_exits"] == 0
+    tr.set_option(grt.OPT_BUNDLE_ROUNDS, 2)
+    tr.set_option(grt.OPT_BUNDLE_BUDGET, 1024)
+    tr.set_option(grt.OPT_KERNEL, 3)
+    a8, af = tr.render(p, want_f32=True)
+    assert (a8 == u8).all() and (af == f32).all()
+    tr.set_option(grt.OPT_KERNEL, 1)
+    x0, y0, x1, y1 = 880, 460, 1040, 620  # the sphere's centre
+    w8 = torch.zeros_like(u8); wf = torch.zeros_like(f32)
+    tr.render(p, window=(x0, y0, x1, y1), out_u8=w8, out_f32=wf)
+    assert (w8[y0:y1, x0:x1] == u8[y0:y1, x0:x1]).all() and (wf[y0:y1, x0:x1] == f32[y0:y1, x0:x1]).all()
+    tr.close()
+
+
 def test_anisotropic_scene_crowded_frontier_kernel_independence():
     """Needle / pancake Gaussians at scale (per-axis log-scale noise sigma 1.2 on 300 k Gaussians): proxies that span a
     large part of the scene overlap by the hundred, the tile kernel's frontier spills to its LDS bag and is rebalanced
