@@ -359,6 +359,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
 // ------------------------------------------------------------------------------------------------
 int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
 {
+    if (c) c->scene_epoch++;
     if (!c || (n && (!g || !g->pos || !g->scale || !g->quat || !g->opacity || !g->sh))) {
         if (c) c->err = "grt_upload_gaussians: null argument";
         return GRT_ERR_INVALID;
@@ -390,6 +391,7 @@ int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
 
 int grt_build_bvh(grt_ctx* c, float alpha_min)
 {
+    if (c) c->scene_epoch++;
     if (!c) return GRT_ERR_INVALID;
     if (!(alpha_min > 0.0f)) { c->err = "grt_build_bvh: alpha_min must be > 0"; return GRT_ERR_INVALID; }
     CHK(c, hipSetDevice(c->device));
@@ -454,6 +456,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
 
 int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 {
+    if (c) c->scene_epoch++;
     if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
     CHK(c, hipSetDevice(c->device));
     CHK(c, hipStreamSynchronize(c->stream));
@@ -522,6 +525,7 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 // hierarchy and only re-fits its boxes.  Fails with GRT_ERR_INVALID when the counts differ from the last grt_set_meshes.
 int grt_update_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 {
+    if (c) c->scene_epoch++;
     if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
     CHK(c, hipSetDevice(c->device));
     uint64_t nv = 0, nf = 0;
@@ -662,6 +666,13 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_cap = n_units;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
+    if (same && c->order_ready && c->order_epoch == c->scene_epoch && memcmp(&c->order_params, &a.p, sizeof(grt_params)) == 0) {
+        // the very frame the order was made from (same scene, camera, options): a tile's cost does not depend on the launch
+        // order, so this frame would measure the same costs and make the same order again — keep it, collect nothing
+        a.order = c->d_order;
+        if (c->order_split) a.n_heavy = c->d_n_heavy;
+        return GRT_OK;
+    }
     if (same) {
         // (normally already there: do_launch orders the units for the next frame right behind this frame's kernels,
         //  where it fills the gap between two frames instead of delaying the next one)
@@ -799,6 +810,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order, behind this frame (not in its timing)
         if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
             c->order_ready = true;
+            c->order_params = a.p;
+            c->order_epoch = c->scene_epoch;
             // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)
             if (hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_units, s) == hipSuccess) c->cost_zeroed = true;
         }

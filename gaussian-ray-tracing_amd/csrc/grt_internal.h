@@ -229,6 +229,9 @@ struct grt_ctx {
     bool cost_valid = false;
     bool order_ready = false; // d_order already holds the order for the next frame with this geometry (do_launch, post-frame)
     bool order_split = false;
+    grt_params order_params{};   // the frame d_order was made from ...
+    uint64_t order_epoch = 0;    // ... and the scene it showed (scene_epoch: bumped by every upload / build / mesh call)
+    uint64_t scene_epoch = 1;
     bool cost_zeroed = false, ovf_zeroed = false; // d_cost / d_ovf_next were zeroed behind the last frame
     // wavefront buffers (allocated on first mesh frame)
     float4 *d_prec = nullptr, *d_queue = nullptr; // d_queue: two queues (ping-pong between the stages)
