@@ -85,7 +85,7 @@ class FrameLoop:
     None; `local_gather` replaces the collective by a local copy (one-rank emulation on one GPU)."""
 
     def __init__(self, torch, tiles, width, height, world, rank, slots, device, render_full, render_tiles, dist=None,
-                 local_gather=False, streams=None):
+                 local_gather=False, streams=None, assemble=None):
         self.torch, self.tiles, self.W, self.H = torch, tiles, width, height
         self.world, self.rank, self.D, self.dist, self.local = world, rank, slots, dist, local_gather
         self.render_full, self.render_tiles = render_full, render_tiles
@@ -97,8 +97,12 @@ class FrameLoop:
         if world > 1:
             self.mines = [torch.zeros((self.max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
             root = rank == 0 or local_gather
-            self.gathereds = [[torch.zeros_like(self.mines[0]) for _ in range(world)] if root else None for _ in range(slots)]
+            # ONE buffer per slot, [world][max_cnt][tile][tile][3]; the collective writes rank r's tiles into its slice r
+            self.gbufs = [torch.zeros((world,) + tuple(self.mines[0].shape), dtype=torch.uint8, device=device) if root else None
+                          for _ in range(slots)]
+            self.gathereds = [[g[r] for r in range(world)] if root else None for g in self.gbufs]
         self.streams = streams
+        self.assemble = assemble  # assemble(slot, gbuf, world, max_cnt, frame): the HIP un-permute kernel; None = torch views
 
     def step(self, i=0):
         k = i % self.D
@@ -114,7 +118,10 @@ class FrameLoop:
                 # RCCL: 7 peers -> 7 distinct xGMI links into rank 0, <= 0.8 MB each at 1080p
                 self.dist.gather(self.mines[k], self.gathereds[k], dst=0)
             if self.rank == 0 or self.local:
-                self.frames[k].copy_(self.tiles.assemble(self.gathereds[k], self.W, self.H, TILE))
+                if self.assemble is not None:
+                    self.assemble(k, self.gbufs[k], self.world, self.max_cnt, self.frames[k])
+                else:
+                    self.frames[k].copy_(self.tiles.assemble(self.gathereds[k], self.W, self.H, TILE))
 
 
 class _Null:
@@ -220,7 +227,8 @@ def main():
         return FrameLoop(torch, tiles, W, H, t_world, t_rank, depth, dev,
                          render_full=lambda k, frame: trs[k].render(p, out_u8=frame, want_u8=True),
                          render_tiles=lambda k, first, stride, cnt, out: trs[k].render_tiles(p, TILE, TILE, first, stride, cnt, out_u8=out),
-                         dist=dist, local_gather=bool(emul), streams=streams)
+                         dist=dist, local_gather=bool(emul), streams=streams,
+                         assemble=lambda k, g, world_, max_cnt, frame: trs[k].assemble_tiles(g, world_, max_cnt, TILE, W, H, frame))
 
     loop = make_loop(D)
     frame = loop.frames[0]

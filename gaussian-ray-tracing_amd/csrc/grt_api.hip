@@ -859,6 +859,35 @@ int grt_render_tiles(grt_ctx* c, const grt_params* p, uint8_t* d_rgb8, float* d_
     return do_launch(c, a, stream);
 }
 
+// rank 0 of an N-rank frame: the gathered compact buffers back into screen order ("rank 0 un-permutes tiles
+// with a trivial copy kernel").  Tile t of the row-major tile grid was rendered by rank t % world as its tile t / world.
+__global__ void k_assemble_tiles(const uint8_t* __restrict__ g, uint32_t world, uint32_t max_cnt, uint32_t tile_w, uint32_t tile_h,
+                                 uint32_t tiles_x, uint32_t width, uint32_t height, uint8_t* __restrict__ out)
+{
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x, py = blockIdx.y;
+    if (px >= width || py >= height) return;
+    const uint32_t t = (py / tile_h) * tiles_x + px / tile_w;
+    const uint32_t r = t % world, j = t / world;
+    const size_t src = ((((size_t)r * max_cnt + j) * tile_h + py % tile_h) * tile_w + px % tile_w) * 3;
+    const size_t dst = ((size_t)py * width + px) * 3;
+    out[dst] = g[src]; out[dst + 1] = g[src + 1]; out[dst + 2] = g[src + 2];
+}
+
+int grt_assemble_tiles(grt_ctx* c, const uint8_t* d_gathered, uint32_t world, uint32_t max_cnt, uint32_t tile_w, uint32_t tile_h,
+                       uint32_t width, uint32_t height, uint8_t* d_rgb8, void* stream)
+{
+    if (!c) return GRT_ERR_INVALID;
+    if (!d_gathered || !d_rgb8 || !world || !tile_w || !tile_h || !width || !height) { c->err = "grt_assemble_tiles: bad arguments"; return GRT_ERR_INVALID; }
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    if ((uint64_t)max_cnt * world < (uint64_t)tiles_x * tiles_y) { c->err = "grt_assemble_tiles: world x max_cnt tiles do not cover the frame"; return GRT_ERR_INVALID; }
+    CHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipLaunchKernelGGL(k_assemble_tiles, dim3((width + 255) / 256, height), dim3(256), 0, s, d_gathered, world, max_cnt, tile_w, tile_h,
+                       tiles_x, width, height, d_rgb8);
+    CHK(c, hipGetLastError());
+    return GRT_OK;
+}
+
 int grt_render_rays(grt_ctx* c, const grt_params* p, const float* d_rays, uint64_t n, float* d_rgbf, void* stream)
 {
     RenderArgs a;

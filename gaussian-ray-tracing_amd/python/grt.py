@@ -56,7 +56,7 @@ KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERN
 
 EXPORTS = [
     "grt_create", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
-    "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_render_rays", "grt_sync",
+    "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_assemble_tiles", "grt_render_rays", "grt_sync",
     "grt_get_counters", "grt_last_kernel_ms", "grt_host_activate", "grt_host_uvw_frame", "grt_host_synth_scene",
     "grt_host_ply_count", "grt_host_ply_read", "grt_host_ply_write", "grt_host_last_error",
     "grt_host_primitive_counts", "grt_host_primitive_fill", "grt_host_obj_count", "grt_host_obj_read", "grt_host_obj_write",
@@ -94,6 +94,7 @@ def lib():
         L.grt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
         L.grt_render.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, vp]
         L.grt_render_tiles.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, u32, vp]
+        L.grt_assemble_tiles.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
         L.grt_render_rays.argtypes = [vp, C.POINTER(Params), vp, u64, vp, vp]
         L.grt_sync.argtypes = [vp]
         L.grt_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -337,6 +338,11 @@ class Tracer:
         self._check(lib().grt_render_tiles(self._h, C.byref(params), out_u8.data_ptr() if out_u8 is not None else None,
                                            out_f32.data_ptr() if out_f32 is not None else None, tile_w, tile_h, first,
                                            stride, count, self._stream()))
+
+    def assemble_tiles(self, gathered, world, max_cnt, tile, width, height, out_u8):
+        """gathered: ONE uint8 tensor [world][max_cnt][tile][tile][3] (the ranks' compact buffers) -> out_u8 [height][width][3]."""
+        self._check(lib().grt_assemble_tiles(self._h, gathered.data_ptr(), world, max_cnt, tile, tile, width, height,
+                                             out_u8.data_ptr(), self._stream()))
 
     def render_rays(self, params, rays, out=None):
         t = self._torch

@@ -19,6 +19,7 @@
  *   grt_render                    render(): param upload + optixLaunch of  src/GaussianTracer.cpp:508-538,
  *                                 raygen/anyhit/closesthit/miss              shaders/tracer.cu:17-187
  *   grt_render_tiles              (new) screen-tile sharding for N GPUs    SURVEY.md §8(e)
+ *   grt_assemble_tiles            (new) rank 0's un-permute of the gathered tiles   SURVEY.md §8(e)
  *   grt_render_rays               (new) ray-buffer input for parity tests  SURVEY.md §7 hard part 1
  *   grt_sync                      CUDA_SYNC_CHECK()                        src/GaussianTracer.cpp:537
  *   grt_host_*                    host-side pieces the facade shares with ctypes users:
@@ -182,6 +183,11 @@ GRT_API int grt_render(grt_ctx* ctx, const grt_params* p, uint8_t* d_rgb8, float
 GRT_API int grt_render_tiles(grt_ctx* ctx, const grt_params* p, uint8_t* d_rgb8, float* d_rgbf, uint32_t tile_w,
                              uint32_t tile_h, uint32_t first_tile, uint32_t tile_stride, uint32_t n_tiles,
                              void* stream);
+/* Rank 0 of an N-rank frame ("rank 0 un-permutes tiles with a trivial copy kernel"): d_gathered holds the
+ * ranks' compact buffers back to back, [world][max_cnt][tile_h][tile_w][3] (tile t of the grid = tile t / world of rank
+ * t % world, as grt_render_tiles with first_tile = rank, tile_stride = world writes them); d_rgb8 receives the frame. */
+GRT_API int grt_assemble_tiles(grt_ctx* ctx, const uint8_t* d_gathered, uint32_t world, uint32_t max_cnt, uint32_t tile_w,
+                               uint32_t tile_h, uint32_t width, uint32_t height, uint8_t* d_rgb8, void* stream);
 /* d_rays[n][6] = origin, direction (device); d_rgbf[n][3] */
 GRT_API int grt_render_rays(grt_ctx* ctx, const grt_params* p, const float* d_rays, uint64_t n, float* d_rgbf,
                             void* stream);

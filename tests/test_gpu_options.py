@@ -100,3 +100,22 @@ def test_eye_records_follow_the_camera_and_the_scene():
     ref_u8, ref_f32, _ = sc2.render(to_oracle_params(q))
     compare_frames(f32, ref_f32, u8, ref_u8)
     tr.close()
+
+
+def test_assemble_tiles_equals_the_torch_unpermute():
+    """grt_assemble_tiles (rank 0's un-permute kernel) against tiles.assemble on random bytes: ragged frame, 3 ranks."""
+    import tiles
+    import torch
+    W, H, T, world = 200, 136, 32, 3  # 7 x 5 tiles, ragged on both sides
+    tx, ty = tiles.grid(W, H, T)
+    _, _, _, max_cnt = tiles.my_tiles(tx * ty, world, 0)
+    g = torch.randint(0, 256, (world, max_cnt, T, T, 3), dtype=torch.uint8, device="cuda:0")
+    ref = tiles.assemble([g[r] for r in range(world)], W, H, T)
+    t = grt.Tracer(0)
+    out = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda:0")
+    t.assemble_tiles(g, world, max_cnt, T, W, H, out)
+    t.sync()
+    assert bool((out == ref).all())
+    with pytest.raises(grt.GrtError):
+        t.assemble_tiles(g, world, 1, T, W, H, out)  # world x max_cnt tiles do not cover the frame
+    t.close()
