@@ -422,14 +422,16 @@ def test_moved_mesh_refit_matches_rebuild_and_oracle(tr):
     tr.set_meshes([])
 
 
-@pytest.mark.parametrize("mesh_type", [grt.MIRROR, grt.GLASS])
-def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type):
+@pytest.mark.parametrize("mesh_type,sh_degree", [(grt.MIRROR, 0), (grt.GLASS, 0), (grt.GLASS, 3)])
+def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
     """Mesh frames on the tile kernel: the bounced rays go through k_queue_mesh + the bundle kernel (a wave per 8x8
     tile's rays), chunks over budget through the one-ray-per-wave mode, whatever still bounces after the bundle rounds
     through the per-lane kernel.  Every split of the work between the three must give the per-lane megakernel's frame
     bit for bit, and the oracle's within tolerance: 0 rounds (per-lane only), budget 1 (every ray alone on a wave),
-    default, 4 rounds with a small budget (lone rays that keep bouncing -> the packed queue)."""
-    acts, p, sc, op, center = make_scene(51, 20000, 192, 160, scale_boost=0.7, mesh_type=mesh_type, max_bounces=8)
+    default, 4 rounds with a small budget (lone rays that keep bouncing -> the packed queue); also with degree-3 SH
+    (the lone-ray mode evaluates an event's radiance when it is inserted, not when it is composited)."""
+    acts, p, sc, op, center = make_scene(51, 20000, 192, 160, scale_boost=0.7, mesh_type=mesh_type, max_bounces=8,
+                                         sh_degree=sh_degree)
     eye = np.float32([0, 0, 3])
     base = (0.25 * center + 0.75 * eye).astype(np.float32)
     v1, n1, f1 = grt.sphere_mesh(base + np.float32([0.25, 0, 0]), tess_u=48, tess_v=24)
