@@ -676,12 +676,17 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
     if (same) {
         // (normally already there: do_launch orders the units for the next frame right behind this frame's kernels,
         //  where it fills the gap between two frames instead of delaying the next one)
-        if (!c->order_ready) {
+        if (!c->order_ready && !c->cost_zeroed) { // the costs of the last frame are still in d_cost
             int rc = order_from_costs(c, a, n_units, s, &c->order_split);
             if (rc != GRT_OK) return rc;
+            c->order_valid = true;
         }
-        a.order = c->d_order;
-        if (c->order_split) a.n_heavy = c->d_n_heavy;
+        // (an option was changed after the costs were consumed and zeroed: the order made from them is still the best
+        //  there is — this frame collects costs again)
+        if (c->order_valid) {
+            a.order = c->d_order;
+            if (c->order_split) a.n_heavy = c->d_n_heavy;
+        }
     } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && c->n && (a.mode == 0 || a.mode == 1)) {
         // no costs of a previous frame with this geometry: order the tiles by the number of particle centres that
         // project into them (dense tiles first), so that the first frame's long tiles do not start last
@@ -698,6 +703,10 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         int rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
+        c->order_valid = true;
+        c->order_split = false;
+    } else {
+        c->order_valid = false; // nothing in d_order is meant for this launch geometry
     }
     if (!(same && c->cost_zeroed)) CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
     a.cost = c->d_cost;
@@ -810,6 +819,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order, behind this frame (not in its timing)
         if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
             c->order_ready = true;
+            c->order_valid = true;
             c->order_params = a.p;
             c->order_epoch = c->scene_epoch;
             // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)

@@ -229,6 +229,7 @@ struct grt_ctx {
     bool cost_valid = false;
     bool order_ready = false; // d_order already holds the order for the next frame with this geometry (do_launch, post-frame)
     bool order_split = false;
+    bool order_valid = false; // d_order is a permutation of the units of cost_sig's launch geometry
     grt_params order_params{};   // the frame d_order was made from ...
     uint64_t order_epoch = 0;    // ... and the scene it showed (scene_epoch: bumped by every upload / build / mesh call)
     uint64_t scene_epoch = 1;
