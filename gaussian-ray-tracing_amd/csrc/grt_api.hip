@@ -340,6 +340,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
         c->opt_bundle_rounds = value;
     }
     else if (option == GRT_OPT_BUNDLE_BUDGET) { c->opt_bundle_budget = std::max(1, value); }
+    else if (option == GRT_OPT_LANE_BUDGET) { c->opt_lane_budget = std::max(1, value); }
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { g_size_classes = value ? 1 : 0; }
@@ -733,9 +734,11 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
     a.prec = nullptr; a.queue = nullptr; a.qcount = nullptr;
     a.queue_in = nullptr; a.qcount_in = nullptr; a.queue_alt = nullptr;
-    a.heavy = nullptr; a.hcount = nullptr; a.hnext = nullptr; a.fqueue = nullptr; a.fcount = nullptr; a.queue_in_packed = 0;
+    a.heavy = nullptr; a.hcount = nullptr; a.hnext = nullptr; a.fqueue = nullptr; a.fcount = nullptr;
     a.bundle_rounds = (uint32_t)c->opt_bundle_rounds;
     a.bundle_budget = (uint32_t)c->opt_bundle_budget;
+    a.lane_budget = (uint32_t)c->opt_lane_budget;
+    a.single_own_mesh = 0;
     a.single_look = (float)c->opt_single_look / 1024.0f;
     a.single_band = (float)c->opt_single_band / 1024.0f;
     if (c->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)

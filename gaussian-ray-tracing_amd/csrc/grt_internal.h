@@ -121,12 +121,14 @@ struct RenderArgs {
     float4* queue_alt;        // the second queue (launch_render ping-pongs between `queue` and this one)
     uint32_t bundle_rounds;   // bounce iterations on the bundle kernel before k_bounce finishes the rest (tile kernel only)
     uint32_t bundle_budget;   // steps a chunk may take on the bundle kernel before its rays are traced one per wave
-    uint32_t* heavy;          // [n_blocks*256] entries of queue_in whose chunk gave up (written by mode 1, read by mode 2)
-    uint32_t* hcount;
+    uint32_t* heavy;          // [n_blocks*256] entries of queue_in whose chunk gave up (written by mode 1, read by mode 2;
+    uint32_t* hcount;         //   nullptr for mode 2 = the entries 0 .. *hcount - 1 of queue_in themselves)
     uint32_t* hnext;          // mode 2: next entry of the heavy list to be drawn (zeroed with the other counters)
-    float4* fqueue;           // [n_blocks*256][4] PACKED queue of the lone rays that go on (read by k_bounce only)
+    float4* fqueue;           // [n_blocks*256][4] PACKED retry queue: rays whose segment went over the lane budget in k_bounce
+                              // (state at the start of that iteration), finished by the last one-ray-per-wave launch
     uint32_t* fcount;
-    uint32_t queue_in_packed; // k_bounce: *qcount_in counts entries, not 64-entry chunks
+    uint32_t lane_budget;     // k_bounce: iterations one Gaussian segment may take before its ray goes to the retry queue
+    uint32_t single_own_mesh; // mode 2: the rays come from the retry queue (no mesh-hit record: the wave traces the mesh)
     float single_look, single_band; // look-ahead / band of the one-ray-per-wave mode
 };
 
@@ -146,9 +148,9 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
 constexpr int kNumCounters = 8;
 constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
-// round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the packed queue of lone rays,
-// [2R+2 .. 3R+1] the draw counter of round r's one-ray-per-wave launch
-constexpr int kWfCounters = 3 * kMaxBundleRounds + 2;
+// round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the retry queue, [2R+2 .. 3R+1] the draw
+// counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
+constexpr int kWfCounters = 3 * kMaxBundleRounds + 3;
 #ifndef GRT_TILE_OVF
 #define GRT_TILE_OVF 96
 #endif
@@ -239,6 +241,7 @@ struct grt_ctx {
     uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)
     int opt_bundle_rounds = 2; // bounce iterations traced by the wave-per-bundle kernel before the per-lane kernel finishes
     int opt_bundle_budget = 1024;
+    int opt_lane_budget = 128;
     int opt_single_look = 1024, opt_single_band = 256; // 1/1024
     uint32_t* d_heavy = nullptr;
     float4* d_fqueue = nullptr;

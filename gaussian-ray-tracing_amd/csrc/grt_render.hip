@@ -14,6 +14,7 @@
 
 #include "grt_device.h"
 #include "grt_internal.h"
+#include "grt_mesh.h"
 
 namespace grt {
 
@@ -53,9 +54,11 @@ __device__ __forceinline__ void kbuf_insert(KBuf<KK>& kb, uint64_t key, float al
 }
 
 // one k-nearest round: traceGPs + __anyhit__ (shaders/tracer.cuh:289-326, shaders/tracer.cu:136-153)
+// (limit: value of c.iters at which the segment gives up; false = gave up)
 template <bool COUNT, int KK>
-__device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
-                                          const rayinv& ri, uint64_t last_key, float t_hi, KBuf<KK>& kb, Cnt& c)
+__device__ __forceinline__ bool gps_round(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
+                                          const rayinv& ri, uint64_t last_key, float t_hi, KBuf<KK>& kb, Cnt& c,
+                                          uint32_t limit)
 {
 #pragma unroll
     for (int i = 0; i < KK; i++) {
@@ -68,6 +71,7 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
     uint32_t cur = a.root_ref;
     while (true) {
         c.iters++;
+        if (c.iters > limit) return false;
         if (cur & kLeafBit) {
             const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
             for (uint32_t j = 0; j < cnt; j++) {
@@ -128,19 +132,21 @@ __device__ __forceinline__ void gps_round(const RenderArgs& a, uint32_t* __restr
             }
         }
     }
+    return true;
 }
 
 // trace() — shaders/tracer.cuh:328-373
 template <bool COUNT, int KK>
-__device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
-                                                float t_min, float t_max, float& density, f3& radiance, Cnt& c)
+__device__ __forceinline__ bool trace_gaussians(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
+                                                float t_min, float t_max, float& density, f3& radiance, Cnt& c,
+                                                uint32_t limit = 0xFFFFFFFFu)
 {
     float T = 1.0f - density;
     const float epsT = 1e-9f;
     float lastT = t_min;
     radiance = mk3(0.0f, 0.0f, 0.0f);
     if (COUNT) c.segments++;
-    if (a.root_ref == kNoRoot) return; // no hittable particle: density unchanged
+    if (a.root_ref == kNoRoot) return true; // no hittable particle: density unchanged
     const f3 dn = normalize3(d);
     const rayinv ri = mk_rayinv(o, d);
     uint64_t last_key = mk_key(lastT + epsT, 0x7FFFFFFFu, 1);
@@ -148,7 +154,7 @@ __device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* _
     const float minT = a.p.minTransmittance;
     KBuf<KK> kb;
     while (lastT <= t_max && T > minT) {
-        gps_round<COUNT, KK>(a, stk, o, d, ri, last_key, t_hi, kb, c);
+        if (!gps_round<COUNT, KK>(a, stk, o, d, ri, last_key, t_hi, kb, c, limit)) return false;
         if (COUNT) c.rounds++;
         if (kb.key[0] == kKeyInvalid) break;
 #pragma unroll
@@ -175,122 +181,24 @@ __device__ __forceinline__ void trace_gaussians(const RenderArgs& a, uint32_t* _
         last_key = kb.key[KK - 1];
     }
     density = 1.0f - T;
+    return true;
 }
 
-// traceMesh: closest triangle in (tmin, tmax) — shaders/tracer.cuh:266-287
-struct MeshHit { bool hit; float t, u, v; uint32_t face; };
-
+// traceMesh on a per-lane LDS stack (grt_mesh.h)
 template <bool COUNT>
 __device__ __forceinline__ MeshHit mesh_closest(const RenderArgs& a, uint32_t* __restrict__ stk, f3 o, f3 d,
                                                 float tmin, float tmax, Cnt& c)
 {
-    MeshHit best{false, 0.f, 0.f, 0.f, 0u};
-    if (a.mroot == kNoRoot) return best; // mesh_handle == 0 => miss
-    const rayinv ri = mk_rayinv(o, d);
-    uint32_t sp = 0, cur = a.mroot;
-    while (true) {
-        c.iters++;
-        if (cur & kLeafBit) {
-            const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
-            for (uint32_t j = 0; j < cnt; j++) {
-                const float4* __restrict__ tr = a.tri + (size_t)(first + j) * 3;
-                const float4 t0 = tr[0], t1 = tr[1], t2 = tr[2];
-                const uint32_t face = __float_as_uint(t0.w);
-                float t, u, v;
-                if (tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), o, d, t, u, v)) {
-                    const bool inside = (t > tmin) && (t < tmax);
-                    const bool tie = best.hit && (t == best.t) && (face < best.face);
-                    if (inside || tie) {
-                        best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
-                        tmax = t;
-                    }
-                }
-            }
-            if (sp == 0) break;
-            cur = stk[(--sp) * kBlock];
-        } else {
-            const float4* __restrict__ q = a.mnodes + (size_t)cur * 4;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            if (COUNT) c.node_visits++;
-            float n0, f0, n1, f1;
-            box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
-            box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);
-            const bool h0 = (n0 <= f0) && (f0 >= tmin) && (n0 <= tmax);
-            const bool h1 = (n1 <= f1) && (f1 >= tmin) && (n1 <= tmax);
-            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-            if (h0 && h1) {
-                const bool first0 = n0 <= n1;
-                stk[(sp++) * kBlock] = first0 ? c1 : c0;
-                cur = first0 ? c0 : c1;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else {
-                if (sp == 0) break;
-                cur = stk[(--sp) * kBlock];
-            }
-        }
-    }
-    return best;
-}
-
-// getBarycentricNormal — shaders/tracer.cuh:167-185
-__device__ __forceinline__ f3 bary_normal(const RenderArgs& a, const MeshHit& h)
-{
-    const uint32_t i0 = a.faces[h.face * 3], i1 = a.faces[h.face * 3 + 1], i2 = a.faces[h.face * 3 + 2];
-    const f3 n0 = mk3(a.vnormals[i0 * 3], a.vnormals[i0 * 3 + 1], a.vnormals[i0 * 3 + 2]);
-    const f3 n1 = mk3(a.vnormals[i1 * 3], a.vnormals[i1 * 3 + 1], a.vnormals[i1 * 3 + 2]);
-    const f3 n2 = mk3(a.vnormals[i2 * 3], a.vnormals[i2 * 3 + 1], a.vnormals[i2 * 3 + 2]);
-    const float w0 = 1.0f - h.u - h.v, w1 = h.u, w2 = h.v;
-    return normalize3(add3(add3(mul3s(n0, w0), mul3s(n1, w1)), mul3s(n2, w2)));
-}
-
-enum { LastGaussianPass = 0, GaussianPass = 1, MeshPass = 2, Terminate = 3 }; // src/Parameters.h:85-91
-
-// RayPayload + RayData (shaders/tracer.cuh:24-56) as far as the bounce loop carries them
-struct RayState {
-    f3 curO, curD, accumColor;
-    float accumAlpha, blocking, density;
-    uint32_t numBounces, timeout;
-};
-
-// __closesthit__closesthit / __miss__miss for one mesh trace (shaders/tracer.cu:112-122,155-187): decides the state,
-// the upper end of this iteration's Gaussian segment and the next ray
-__device__ __forceinline__ void mesh_shade(const RenderArgs& a, const MeshHit& mh, f3 ray_o, f3 ray_d, int& state,
-                                           float& seg_tmax, f3& normal, f3& curO, f3& curD, uint32_t& numBounces)
-{
-    normal = mk3(0, 0, 0);
-    seg_tmax = a.p.t_max; // LastGaussianPass traces to t_max (shaders/tracer.cu:70-75)
-    if (mh.hit) {
-        float t_hit = mh.t;
-        normal = bary_normal(a, mh);
-        f3 newDir = mk3(0, 0, 0);
-        state = GaussianPass;
-        seg_tmax = t_hit;
-        if (a.p.type == GRT_MIRROR) { // renderMirror, shaders/tracer.cuh:396-404
-            newDir = reflect3(ray_d, normal);
-            numBounces += 1;
-        } else if (a.p.type == GRT_NORMAL) { // renderNormal traces [t_min, t_hit] itself, shaders/tracer.cuh:406-429
-            state = Terminate;
-        } else if (a.p.type == GRT_GLASS) { // renderGlass, shaders/tracer.cuh:466-482
-            const float n1 = 1.0003f, n2 = 1.5f;
-            if (refract_dir(ray_d, normal, n2 / n1, newDir)) t_hit += kRefractionEpsShift;
-            else numBounces += 1;
-            seg_tmax = t_hit; // payload.t_hit carries the shifted value (shaders/tracer.cu:180)
-        }
-        curO = add3(ray_o, mul3s(ray_d, t_hit));
-        curD = newDir;
-    } else { // __miss__miss
-        curO = mk3(0, 0, 0);
-        curD = mk3(0, 0, 0);
-        state = LastGaussianPass;
-    }
+    return mesh_closest_t<COUNT, kBlock>(a, stk, o, d, tmin, tmax, c.iters, c.node_visits);
 }
 
 // __raygen__raygeneration bounce loop (shaders/tracer.cu:58-106), resumable from a RayState
+// seg_budget: iterations ONE Gaussian segment may take; a ray over it stops, *retry receives its state at the start of
+// that iteration (nothing of the iteration is kept, counters included) and *gave_up is set: such a ray is one of the few
+// with hundreds of events, and is finished wave-cooperatively (tile kernel, one ray per wave)
 template <bool COUNT, int KK>
-__device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, RayState st, Cnt& c)
+__device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restrict__ stk, RayState st, Cnt& c,
+                                        uint32_t seg_budget = 0xFFFFFFFFu, RayState* retry = nullptr, bool* gave_up = nullptr)
 {
     f3 curO = st.curO, curD = st.curD;
     f3 accumColor = st.accumColor, directLight = mk3(0, 0, 0);
@@ -298,6 +206,9 @@ __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restric
     uint32_t numBounces = st.numBounces, timeout = st.timeout;
     while (length3(curD) > 0.1f && numBounces < a.p.max_bounces) {
         const f3 ray_o = curO, ray_d = curD;
+        const Cnt c0 = c;
+        const uint32_t nb0 = numBounces;
+        const float density0 = density;
         int state = MeshPass;
         const MeshHit mh = mesh_closest<COUNT>(a, stk, ray_o, ray_d, kTraceMeshTmin, kTraceMeshTmax, c);
         f3 normal;
@@ -305,7 +216,15 @@ __device__ __forceinline__ f3 shade_ray(const RenderArgs& a, uint32_t* __restric
         mesh_shade(a, mh, ray_o, ray_d, state, seg_tmax, normal, curO, curD, numBounces);
         // the single Gaussian segment of this iteration (one call site keeps the kernel small)
         f3 rad;
-        trace_gaussians<COUNT, KK>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c);
+        const uint32_t limit = (seg_budget == 0xFFFFFFFFu) ? seg_budget : c.iters + seg_budget;
+        if (!trace_gaussians<COUNT, KK>(a, stk, ray_o, ray_d, a.p.t_min, seg_tmax, density, rad, c, limit)) {
+            c = c0;
+            retry->curO = ray_o; retry->curD = ray_d; retry->accumColor = accumColor;
+            retry->accumAlpha = accumAlpha; retry->blocking = blocking; retry->density = density0;
+            retry->numBounces = nb0; retry->timeout = timeout;
+            *gave_up = true;
+            return accumColor;
+        }
         const float alpha = density;
         if (state == Terminate) { // renderNormal, shaders/tracer.cuh:417-428
             accumColor = add3(accumColor, rad);
@@ -456,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
     Cnt c;
     const uint32_t lane = threadIdx.x & 63u;
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const size_t n_ent = a.queue_in_packed ? (size_t)*a.qcount_in : (size_t)*a.qcount_in * 64u;
+    const size_t n_ent = (size_t)*a.qcount_in * 64u;
     if (((size_t)blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= n_ent) return; // wave-uniform
     float4 q3 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n_ent) q3 = a.queue_in[i * 4 + 3];
@@ -469,14 +388,24 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const RenderArgs a)
         st.accumAlpha = q2.y; st.blocking = q2.z; st.density = q2.w;
         st.numBounces = __float_as_uint(q3.x); st.timeout = __float_as_uint(q3.y) & 0x7FFFFFFFu;
         const size_t out_idx = (size_t)__float_as_uint(q3.z) | ((size_t)__float_as_uint(q3.w) << 32);
-        const f3 col = shade_ray<COUNT, kBounceK>(a, stk, st, c);
-        if (a.outf) {
-            a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
-        }
-        if (a.out8) {
-            a.out8[out_idx * 3] = quantize8(col.x);
-            a.out8[out_idx * 3 + 1] = quantize8(col.y);
-            a.out8[out_idx * 3 + 2] = quantize8(col.z);
+        RayState rt;
+        bool gave_up = false;
+        const f3 col = shade_ray<COUNT, kBounceK>(a, stk, st, c, a.lane_budget, &rt, &gave_up);
+        if (gave_up) { // to the retry queue (packed; read by the one-ray-per-wave launch that follows)
+            float4* q = a.fqueue + (size_t)atomicAdd(a.fcount, 1u) * 4;
+            q[0] = make_float4(rt.curO.x, rt.curO.y, rt.curO.z, rt.curD.x);
+            q[1] = make_float4(rt.curD.y, rt.curD.z, rt.accumColor.x, rt.accumColor.y);
+            q[2] = make_float4(rt.accumColor.z, rt.accumAlpha, rt.blocking, rt.density);
+            q[3] = make_float4(__uint_as_float(rt.numBounces), __uint_as_float(rt.timeout | 0x80000000u), q3.z, q3.w);
+        } else {
+            if (a.outf) {
+                a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
+            }
+            if (a.out8) {
+                a.out8[out_idx * 3] = quantize8(col.x);
+                a.out8[out_idx * 3 + 1] = quantize8(col.y);
+                a.out8[out_idx * 3 + 2] = quantize8(col.z);
+            }
         }
     }
     if (COUNT) {
@@ -625,17 +554,24 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
             b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
             hipLaunchKernelGGL(fq, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
-            rc = launch_render_tile(b, count, true, 1, stream, err);
-            if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err);
+            rc = launch_render_tile(b, count, true, 1, stream, err);          // bundles; chunks over budget -> heavy list
+            if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err); // its rays: one per wave, to their end
             if (rc != GRT_OK) return rc;
             in ^= 1u;
             stage++;
         }
-        b.queue_in = q[in]; b.qcount_in = a.qcount + stage; b.queue_in_packed = 0;
+        // whatever still bounces finishes per lane; a segment over the lane budget sends its ray to the retry queue, and
+        // those rays are finished one per wave (tile kernel only: the other pipelines have no per-child BVH layout)
+        b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
+        b.lane_budget = tile_kernel ? a.lane_budget : 0xFFFFFFFFu;
         hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
-        if (rounds) { // the lone rays that still bounce
-            b.queue_in = a.fqueue; b.qcount_in = b.fcount; b.queue_in_packed = 1;
-            hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+        if (tile_kernel) {
+            RenderArgs s2 = b;
+            s2.queue_in = a.fqueue; s2.heavy = nullptr; s2.hcount = b.fcount; // the retry queue itself is the list
+            s2.hnext = a.qcount + 3 * kMaxBundleRounds + 2;
+            s2.single_own_mesh = 1;                                           // its rays carry no mesh-hit record
+            rc = launch_render_tile(s2, count, true, 2, stream, err);
+            if (rc != GRT_OK) return rc;
         }
         e = hipGetLastError();
         if (e != hipSuccess) {

@@ -34,6 +34,7 @@
 
 #include "grt_device.h"
 #include "grt_internal.h"
+#include "grt_mesh.h"
 #include "grt_wave.h"
 
 namespace grt {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
     bool in_frame = false;
     bool aborted = false; // MODE 1: over the step budget
     // BUNDLE: this lane's entry of the incoming queue (MODE 2: the wave's ONE ray, on lane 0)
-    const size_t ent = SINGLE ? (size_t)a.heavy[unit] : (size_t)unit * 64u + lane;
+    const size_t ent = SINGLE ? (a.heavy ? (size_t)a.heavy[unit] : (size_t)unit) : (size_t)unit * 64u + lane;
     const size_t qi = ent * 4;
     if (BUNDLE) {
         const float4 q3 = a.queue_in[qi + 3];
@@ -301,7 +302,19 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
     float seg_tmax = a.p.t_max;
     uint32_t pflags = 0;
     f3 nextO = mk3(0, 0, 0), nextD = mk3(0, 0, 0), hitN = mk3(0, 0, 0);
-    if (MESH) { // stage 1 (k_primary_mesh / k_queue_mesh) already traced the mesh for this ray
+    if (SINGLE && a.single_own_mesh) { // a ray from the retry queue of k_bounce: no mesh-hit record yet
+        if (have_ray) {
+            uint32_t it_ = 0, nv_ = 0;
+            const MeshHit mh = mesh_closest_t<COUNT, 1>(a, dstack, o, d, kTraceMeshTmin, kTraceMeshTmax, it_, nv_);
+            if (COUNT && tally) c.node_visits += nv_;
+            int st_ = MeshPass;
+            uint32_t nb_ = __float_as_uint(a.queue_in[qi + 3].x);
+            f3 nrm_;
+            mesh_shade(a, mh, o, d, st_, seg_tmax, nrm_, nextO, nextD, nb_);
+            hitN = nrm_;
+            pflags = (uint32_t)st_ | (nb_ << 8) | (1u << 16);
+        }
+    } else if (MESH) { // stage 1 (k_primary_mesh / k_queue_mesh) already traced the mesh for this ray
         const size_t pi = BUNDLE ? ent * 3 : ((size_t)blk * kBlock + wave * 64u + lane) * 3;
         const float4 pr0 = a.prec[pi], pr1 = a.prec[pi + 1], pr2 = a.prec[pi + 2];
         seg_tmax = pr0.x;
@@ -312,6 +325,24 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
         have_ray = have_ray && ((pflags >> 16) & 1u);
     }
 
+    f3 col = mk3(0.0f, 0.0f, 0.0f);
+    bool cont = false; // MESH: the ray goes on bouncing (stage 3)
+    f3 accumColor = mk3(0, 0, 0);
+    float accumAlpha = 0.0f, blocking = 0.0f;
+    uint32_t timeout = 0;
+    if (BUNDLE && in_frame) { // the accumulators of the iterations before this one
+        const float4 q1 = a.queue_in[qi + 1], q2 = a.queue_in[qi + 2], q3 = a.queue_in[qi + 3];
+        accumColor = mk3(q1.z, q1.w, q2.x);
+        accumAlpha = q2.y;
+        blocking = q2.z;
+        timeout = __float_as_uint(q3.y) & 0x7FFFFFFFu;
+        col = accumColor;
+    }
+    bool gave_up = false; // MODE 1: the chunk went over its budget
+    float density = 0.0f;
+    // MODE 2 keeps its ray until it ends: every trip of this loop is one iteration of the reference's bounce loop
+    // (shaders/tracer.cu:58-106); the other modes make one trip and queue the rays that go on
+    for (;;) {
     // ---- trace() for the whole wave (shaders/tracer.cuh:328-373), density starts at 0 ----
     const float minT = a.p.minTransmittance;
     float T = 1.0f - density_in; // the payload's density carries over from segment to segment (shaders/tracer.cuh:331)
@@ -734,7 +765,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                     watchdog = true;
                     break;
                 }
-                if (MODE == 1 && iters + work > a.bundle_budget) { // not a bundle worth the name: its rays go one per wave
+                if (MODE == 1 && iters + work > a.bundle_budget) { // not a bundle worth the name: it is split, or its rays go one per wave
                     aborted = true;
                     break;
                 }
@@ -1031,24 +1062,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
         if (lane == 0) base = atomicAdd(a.hcount, (uint32_t)__popcll(vm));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (in_frame) a.heavy[base + lanes_below(vm)] = (uint32_t)ent;
+        gave_up = true;
         break;
     }
     // (no hittable particle: the density is left as it came, shaders/tracer.cuh:328-373 never runs)
-    const float density = (BUNDLE && a.root_ref == kNoRoot) ? density_in : 1.0f - T;
-
-    f3 col = mk3(0.0f, 0.0f, 0.0f);
-    bool cont = false; // MESH: the ray goes on bouncing (stage 3)
-    f3 accumColor = mk3(0, 0, 0);
-    float accumAlpha = 0.0f, blocking = 0.0f;
-    uint32_t timeout = 0;
-    if (BUNDLE && in_frame) { // the accumulators of the iterations before this one
-        const float4 q1 = a.queue_in[qi + 1], q2 = a.queue_in[qi + 2], q3 = a.queue_in[qi + 3];
-        accumColor = mk3(q1.z, q1.w, q2.x);
-        accumAlpha = q2.y;
-        blocking = q2.z;
-        timeout = __float_as_uint(q3.y) & 0x7FFFFFFFu;
-        col = accumColor;
-    }
+    density = (BUNDLE && a.root_ref == kNoRoot) ? density_in : 1.0f - T;
+    cont = false;
     const uint32_t numBounces = (pflags >> 8) & 0xFFu;
     if (have_ray) {
         const float alpha = density;
@@ -1080,21 +1099,33 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
             col = accumColor;
         }
     }
+    if (!(SINGLE && cont)) break;
+    // ---- MODE 2, next iteration: the mesh hit of the new ray.  All 64 lanes hold the same ray and walk the (small) mesh
+    //      tree in step, on ONE stack (the depth-first overflow stack of the frontier is idle between segments) ----
+    o = nextO;
+    d = nextD;
+    density_in = density;
+    {
+        uint32_t it_ = 0, nv_ = 0;
+        const MeshHit mh = mesh_closest_t<COUNT, 1>(a, dstack, o, d, kTraceMeshTmin, kTraceMeshTmax, it_, nv_);
+        if (COUNT && tally) c.node_visits += nv_;
+        int st_ = MeshPass;
+        uint32_t nb_ = numBounces;
+        f3 nrm_;
+        mesh_shade(a, mh, o, d, st_, seg_tmax, nrm_, nextO, nextD, nb_);
+        hitN = nrm_;
+        pflags = (uint32_t)st_ | (nb_ << 8) | (1u << 16);
+    }
+    have_ray = length3(d) > 0.1f;
+    } // bounce loop
+    if (gave_up) break;
+    const uint32_t numBounces = (pflags >> 8) & 0xFFu;
     if (MESH) {
         // ---- the rays that go on: the wave takes ONE 64-entry chunk of the queue (one atomic) and every lane writes
         //      its own slot, so that stage 3 finds the rays of a tile together, as a bundle; bit 31 of the timeout word
         //      marks the slots that carry a ray ----
         const uint64_t mask = wave_ballot(cont);
-        if (SINGLE) { // a lone ray: one slot of the packed queue that only the per-lane kernel reads
-            if (cont && lane == 0u) {
-                float4* q = a.fqueue + (size_t)atomicAdd(a.fcount, 1u) * 4;
-                q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
-                q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);
-                q[2] = make_float4(accumColor.z, accumAlpha, blocking, density);
-                q[3] = make_float4(__uint_as_float(numBounces), __uint_as_float(timeout | 0x80000000u),
-                                   __uint_as_float((uint32_t)out_idx), __uint_as_float((uint32_t)(out_idx >> 32)));
-            }
-        } else if (mask) { // wave-uniform
+        if (!SINGLE && mask) { // wave-uniform (MODE 2 never gets here with a ray that goes on)
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(a.qcount, 1u);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1175,7 +1206,8 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
         if (err) *err = "tile kernel: per-child BVH layout or eye records missing";
         return GRT_ERR_INVALID;
     }
-    if (mode != 0 && (!a.queue_in || !a.qcount_in || !a.prec || !a.queue || !a.qcount || !a.heavy || !a.hcount || !a.fqueue || !a.fcount || !a.hnext)) {
+    if (mode != 0 && (!a.queue_in || !a.qcount_in || !a.prec || !a.queue || !a.qcount || (!a.heavy && mode == 1) || !a.hcount || !a.fqueue ||
+                      !a.fcount || !a.hnext)) {
         if (err) *err = "tile kernel: continuation queues missing";
         return GRT_ERR_INVALID;
     }

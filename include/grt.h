@@ -153,7 +153,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          rays are traced one per wave (a bundle whose rays have spread too far to share work); default
                                          1024.  Same image for every value */,
        GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 1024 = 100 %) */,
-       GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */ };
+       GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
+       GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
+                                         segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
+                                         finishes it (default 128).  Same image for every value */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -426,9 +426,10 @@ def test_moved_mesh_refit_matches_rebuild_and_oracle(tr):
 def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
     """Mesh frames on the tile kernel: the bounced rays go through k_queue_mesh + the bundle kernel (a wave per 8x8
     tile's rays), chunks over budget through the one-ray-per-wave mode, whatever still bounces after the bundle rounds
-    through the per-lane kernel.  Every split of the work between the three must give the per-lane megakernel's frame
-    bit for bit, and the oracle's within tolerance: 0 rounds (per-lane only), budget 1 (every ray alone on a wave),
-    default, 4 rounds with a small budget (lone rays that keep bouncing -> the packed queue); also with degree-3 SH
+    through the per-lane kernel, whose long segments send their ray to the retry queue, to be finished alone on a wave
+    (which then traces the mesh itself).  Every split of the work must give the per-lane megakernel's frame bit for bit,
+    and the oracle's within tolerance: 0 rounds (per-lane only; with retries; every ray retried), budget 1 (every ray
+    alone on a wave, through all its bounces), default, 4 rounds with small budgets; also with degree-3 SH
     (the lone-ray mode evaluates an event's radiance when it is inserted, not when it is composited)."""
     acts, p, sc, op, center = make_scene(51, 20000, 192, 160, scale_boost=0.7, mesh_type=mesh_type, max_bounces=8,
                                          sh_degree=sh_degree)
@@ -447,11 +448,14 @@ def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
     t.upload(acts)
     t.set_meshes(meshes)
     t.set_option(grt.OPT_COUNTERS, 1)
-    routes = {"per-lane only": (0, 1024), "all alone": (2, 1), "default": (2, 1024), "deep": (4, 24), "one round": (1, 64)}
+    routes = {"per-lane only": (0, 1024, 1 << 30), "per-lane, long segments retried alone": (0, 1024, 64),
+              "every ray retried alone (own mesh trace)": (0, 1024, 1), "all alone": (2, 1, 128), "default": (2, 1024, 128),
+              "deep": (4, 24, 16), "one round": (1, 64, 128)}
     segs = set()
-    for name, (rounds, budget) in routes.items():
+    for name, (rounds, budget, lane_budget) in routes.items():
         t.set_option(grt.OPT_BUNDLE_ROUNDS, rounds)
         t.set_option(grt.OPT_BUNDLE_BUDGET, budget)
+        t.set_option(grt.OPT_LANE_BUDGET, lane_budget)
         u8, f32 = t.render(p, want_f32=True)
         cnt = t.counters()
         assert bool((u8 == ref_u8).all()), name
