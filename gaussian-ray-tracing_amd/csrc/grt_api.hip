@@ -736,7 +736,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.queue_in = nullptr; a.qcount_in = nullptr; a.queue_alt = nullptr;
     a.heavy = nullptr; a.hcount = nullptr; a.hnext = nullptr; a.fqueue = nullptr; a.fcount = nullptr;
     a.bundle_rounds = (uint32_t)c->opt_bundle_rounds;
-    a.bundle_budget = (uint32_t)c->opt_bundle_budget;
+    // (rays that went through a glass body are defocused but each of them light: their bundles are worth twice the work
+    //  before they are given up — 1 M scene + glass sphere 8.2 -> 5.9 ms; a mirror's limb bundles are not: 4.0 -> 4.5)
+    a.bundle_budget = (uint32_t)c->opt_bundle_budget * (a.p.type == GRT_GLASS ? 2u : 1u);
     a.lane_budget = (uint32_t)c->opt_lane_budget;
     a.single_own_mesh = 0;
     a.single_look = (float)c->opt_single_look / 1024.0f;
