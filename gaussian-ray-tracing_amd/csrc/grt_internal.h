@@ -242,7 +242,7 @@ struct grt_ctx {
     int opt_bundle_rounds = 2; // bounce iterations traced by the wave-per-bundle kernel before the per-lane kernel finishes
     int opt_bundle_budget = 1024;
     int opt_lane_budget = 128;
-    int opt_single_look = 1024, opt_single_band = 256; // 1/1024
+    int opt_single_look = 256, opt_single_band = 256; // 1/1024
     uint32_t* d_heavy = nullptr;
     float4* d_fqueue = nullptr;
     size_t wf_cap = 0;

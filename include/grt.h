@@ -152,7 +152,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_BUNDLE_BUDGET = 17     /* work (steps + particles fetched + 2 x exact tests) a bundle may take before it is given up and its
                                          rays are traced one per wave (a bundle whose rays have spread too far to share work); default
                                          1024, doubled for GRT_GLASS.  Same image for every value */,
-       GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 1024 = 100 %) */,
+       GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 256 = 25 %) */,
        GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
        GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
                                          segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
