@@ -6,27 +6,32 @@
 // kernel turns that part around:
 //
 //   * CULLING IS DONE WITH LANES = CHILD BOXES.  The tile's rays share the eye and lie inside a thin frustum (four
-//     planes through the eye, from wave reductions over the lanes' directions).  A step takes up to 16 unexpanded
-//     nodes off the frontier at once; lane l loads child (l & 3) of node (l >> 2) — two 16-B vector loads — and tests
-//     that ONE box against the frustum (conservative; culling only) and computes a lower bound lambda of the hit
-//     distance of ANY ray of the tile inside it.  64 boxes per step for ~70 VALU instead of 4 boxes for ~230.
-//     A leaf range expands the same way into its (<= 4) particles, whose boxes sit in pbox[].
-//   * the frontier (unexpanded subtrees AND untested particles) lives in one (lambda, ref) register pair, slot i =
-//     lane i; children are compacted into free slots through a 512-B LDS exchange buffer (rank = v_mbcnt of the
-//     ballot).  A full frontier spills to a depth-first stack in LDS that is drained first with the bound unchanged.
-//   * F = the smallest lambda on the frontier is the FINALITY bound exactly as in the streaming kernel: no unseen
-//     event of any lane can have t < F, so buffered events below F are composited in key order (t, id, entry<exit).
-//   * exact work keeps lanes = rays and the streaming kernel's arithmetic, operation for operation: a particle whose
-//     lambda reaches the front is fetched by scalar loads (64-B record + 16-B eye record) and slab-tested by all
-//     lanes; hits go into the per-lane sorted window (12 keys in registers, payload cells in LDS; the same generated
-//     EXEC-masked insert/shift macros), overflow sets the lane's cutoff and costs another pass.  Frames are therefore
-//     bit-identical to the other kernels'.
+//     planes through the eye, from wave reductions over the lanes' directions).  A node step takes the (<= 8) nearest
+//     unexpanded 8-wide nodes off the frontier at once; lane l loads child (l % 8) of node (l / 8) — two 16-B vector
+//     loads — and tests that ONE box against the frustum (conservative; culling only) and computes a lower bound lambda
+//     of the hit distance of ANY ray of the tile inside it.  64 boxes per step for ~200 VALU instead of 4 boxes for ~230.
+//     A leaf step expands the (<= 16) nearest leaf ranges the same way into their (<= 4) particles, whose boxes sit in
+//     pbox[], and slab-tests the survivors at once.
+//   * the frontier (unexpanded subtrees and leaf ranges) lives in one (lambda, ref) register pair, slot i = lane i;
+//     children are compacted into free slots through a 512-B LDS exchange buffer (rank = v_mbcnt of the ballot).  What
+//     does not fit goes to a 256-entry bag in LDS; a rebalance keeps the nearest entries of (registers + bag) in
+//     registers; only a full bag falls back to a depth-first stack in LDS.
+//   * F = the smallest lambda on the frontier (and in the bag) is the FINALITY bound exactly as in the streaming kernel:
+//     no unseen event of any lane can have t < F, so buffered events below F are composited in key order
+//     (t, id, entry<exit).
+//   * exact work keeps lanes = rays and the streaming kernel's arithmetic, operation for operation: a surviving particle
+//     is fetched by scalar loads (64-B record + 64-B eye record) and slab-tested by all lanes; hits go into the per-lane
+//     sorted window (12 keys in registers, payload cells in LDS; the same generated EXEC-masked insert/shift macros); a
+//     window that overflows spills to the lane's bag in global memory (refilled by a scan; a full bag keeps its nearer
+//     half) and only what is lost for good costs the lane another pass.  Frames are therefore bit-identical to the
+//     other kernels'.
 //   * compositing is deferred until enough lanes have a final event (or a window is about to overflow): one
 //     compositing step costs the same whether 1 or 64 lanes take part.
 //
-// Used for camera rays (window / tile modes), with or without the mesh wavefront pipeline (MESH = true: the primary
-// segment ends at the per-lane mesh hit and the rays that go on are compacted into the continuation queue).
-// Citations (file:line) are into Ray-Studio2/gaussian-ray-tracing.
+// MODE 0: camera rays (window / tile modes), with or without the mesh wavefront pipeline (MESH = true: the primary
+// segment ends at the per-lane mesh hit and the rays that go on are written to the continuation queue, one 64-entry chunk
+// per tile).  MODE 1 / MODE 2: the bounced rays of mesh frames, as per-tile bundles / one ray per wave (below).
+// DESIGN.md 5.2 and 5.5 have the numbers.  Citations (file:line) are into Ray-Studio2/gaussian-ray-tracing.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -220,7 +225,10 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // THAT lane's window together with its colour, so the 64 windows are one pool of 768 pending events; compositing takes
 // the smallest key of the pool (one 64-bit wave minimum per event) and updates the wave-uniform T / radiance.  A ray with
 // a thousand events is then a few dozen steps, not a thousand — it is these rays that bound a per-lane or per-bundle
-// kernel's run time.  Same arithmetic per event, same order: same bits.
+// kernel's run time.  Such a wave keeps its ray to the END: after a segment it traces the mesh itself (all lanes walk the
+// small mesh tree in step on the idle overflow stack) and goes on with the next iteration of the bounce loop.  The same
+// mode finishes the rays of the retry queue (a.single_own_mesh: per-lane segments that went over their budget).
+// Same arithmetic per event, same order: same bits.
 template <bool COUNT, bool SH, bool MESH, int MODE>
 __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_tile(const RenderArgs a)
 {
