@@ -805,7 +805,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         // tile of the launch (3.1 GB for a 1080p frame; only the chunks that are taken are ever touched): a tile that
         // finds the pool empty falls back to another pass — never wrong, but on the default 1 M scene a pool for a
         // quarter of the tiles ran dry and cost the frame 12 %
-        const uint32_t want = std::max(256u, a.n_blocks * 4u);
+        // (capped at 16 GiB: a 4K frame takes 12.4 GB; beyond the cap the tiles that find the pool empty go again)
+        const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
+        const uint32_t want = std::min(cap, std::max(256u, a.n_blocks * 4u));
         if (c->ovf_chunks < want) {
             (void)hipFree(c->d_ovf);
             c->d_ovf = nullptr;
