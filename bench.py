@@ -85,16 +85,19 @@ class FrameLoop:
     None; `local_gather` replaces the collective by a local copy (one-rank emulation on one GPU)."""
 
     def __init__(self, torch, tiles, width, height, world, rank, slots, device, render_full, render_tiles, dist=None,
-                 local_gather=False, streams=None, assemble=None):
+                 local_gather=False, streams=None, assemble=None, force_collective=False):
         self.torch, self.tiles, self.W, self.H = torch, tiles, width, height
         self.world, self.rank, self.D, self.dist, self.local = world, rank, slots, dist, local_gather
+        # one rank normally renders the frame in one launch; force_collective sends it through the N-rank path all the
+        # same (tile list -> compact buffer -> gather -> un-permute): the RCCL branch on a one-GPU box
+        self.single = world == 1 and not force_collective
         self.render_full, self.render_tiles = render_full, render_tiles
         tx, ty = tiles.grid(width, height, TILE)
         self.n_tiles = tx * ty
         _, _, self.my_cnt, self.max_cnt = tiles.my_tiles(self.n_tiles, world, rank)
         self.frames = [torch.zeros((height, width, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
         self.mines = self.gathereds = None
-        if world > 1:
+        if not self.single:
             self.mines = [torch.zeros((self.max_cnt, TILE, TILE, 3), dtype=torch.uint8, device=device) for _ in range(slots)]
             root = rank == 0 or local_gather
             # ONE buffer per slot, [world][max_cnt][tile][tile][3]; the collective writes rank r's tiles into its slice r
@@ -108,7 +111,7 @@ class FrameLoop:
         k = i % self.D
         ctx = self.torch.cuda.stream(self.streams[k]) if self.streams else _Null()
         with ctx:
-            if self.world == 1:
+            if self.single:
                 self.render_full(k, self.frames[k])
                 return
             self.render_tiles(k, self.rank, self.world, self.my_cnt, self.mines[k])
@@ -170,6 +173,9 @@ def main():
                     help="one process, one GPU: do the work of ONE rank of an N-rank run (tile list, frame slots, "
                          "un-permute; the collective is replaced by a local copy) - per-rank time without N GPUs")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="which rank to emulate (default N // 2)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1 under torch.distributed.run: init RCCL and send the frame through the N-rank path "
+                         "(render_tiles -> dist.gather -> assemble) at world size 1")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per rank for `value` (0 = auto: 1 on one GPU, 4 on 2-4 GPUs, 8 on 8+)")
     args = ap.parse_args()
@@ -191,7 +197,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    force = bool(args.force_collective and world == 1 and not args.emulate_ranks)
+    if force and "RANK" not in os.environ:
+        print("bench.py: --force-collective needs the torch.distributed.run environment (RANK / WORLD_SIZE / MASTER_*)", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -211,12 +221,15 @@ def main():
     n_ctx = max(D, D_other)
     t0 = time.time()
     trs = []
-    for _ in range(n_ctx):  # one context per frame slot (the scene is a few hundred MB: replicated per slot)
-        t = grt.Tracer(local_rank)
+    for k in range(n_ctx):  # ONE scene; every further frame slot is a view of it (own stream state, eye records, scratch)
+        if k == 0:
+            t = grt.Tracer(local_rank)
+            t.upload(acts)
+            if mesh is not None:
+                t.set_meshes([mesh])
+        else:
+            t = trs[0].view()
         t.set_option(grt.OPT_KERNEL, args.kernel)
-        t.upload(acts)
-        if mesh is not None:
-            t.set_meshes([mesh])
         trs.append(t)
     tr = trs[0]
     setup_s = (time.time() - t0) / n_ctx
@@ -227,7 +240,7 @@ def main():
         return FrameLoop(torch, tiles, W, H, t_world, t_rank, depth, dev,
                          render_full=lambda k, frame: trs[k].render(p, out_u8=frame, want_u8=True),
                          render_tiles=lambda k, first, stride, cnt, out: trs[k].render_tiles(p, TILE, TILE, first, stride, cnt, out_u8=out),
-                         dist=dist, local_gather=bool(emul), streams=streams,
+                         dist=dist, local_gather=bool(emul), streams=streams, force_collective=force,
                          assemble=lambda k, g, world_, max_cnt, frame: trs[k].assemble_tiles(g, world_, max_cnt, TILE, W, H, frame))
 
     loop = make_loop(D)
@@ -278,7 +291,7 @@ def main():
         one_frame(); one_frame()
     names = ("rays", "segments", "hit_evals", "rounds", "node_visits", "proxy_tests", "rec_fetches", "stall_exits")
     cnt_t = torch.tensor([cnt[k] for k in names], dtype=torch.int64, device=dev)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(cnt_t)
     tot = dict(zip(names, cnt_t.tolist()))
     if emul:  # the other ranks' rays are not traced here: scale this rank's share to the frame
@@ -304,7 +317,7 @@ def main():
             latency = float(np.median(lat))
         for i in range(warmup):
             lp.step(i)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         kms = []
@@ -313,7 +326,7 @@ def main():
             lp.step(i)
             if lp.D == 1:
                 kms.append(tr.last_kernel_ms())  # HIP events on the launch stream; syncs like the reference's render()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - ts
@@ -336,9 +349,12 @@ def main():
         other = (el2, lat2)
         if latency_ms is None:
             latency_ms = lat2
+    for t in trs:
+        t.check()  # raises when a wave gave up on live rays anywhere in the run (sticky device error word)
+    mem = [t.memory_info() for t in trs]
     el = torch.tensor([elapsed, other[0] if other else 0.0], dtype=torch.float64, device=dev)
     km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     elapsed, elapsed_other = float(el[0].item()), float(el[1].item())
@@ -375,10 +391,18 @@ def main():
                                    f"{'fisheye' if fisheye else 'pinhole'}, SH degree {args.sh_degree}"
                                    f"{', per-axis log-scale noise sigma %.1f (needles / pancakes)' % aniso if aniso else ''}"
                                    f"{', reflective sphere (reference primitive, through the OBJ path), <= 2 bounces' if with_mesh else ', no mesh'}",
-                       "tile": f"{TILE}x{TILE} round-robin over ranks, RCCL gather to rank 0" if t_world > 1 else "full frame, one launch",
+                       "tile": (f"{TILE}x{TILE} round-robin over ranks, RCCL gather to rank 0" if (t_world > 1 or force)
+                                else "full frame, one launch"),
                        "emulated_ranks": (f"rank {t_rank} of {t_world} on one GPU, no collective; value = this rank's rays x {t_world} / time"
                                           if emul else None),
+                       "forced_collective": force or None,
                        "frames_in_flight": D,
+                       "device_memory_bytes": {"scene": mem[0]["scene_bytes"], "frame_slots": [m["slot_bytes"] for m in mem],
+                                               "overflow_pool_chunks": [m["overflow_chunks"] for m in mem],
+                                               "overflow_demand_chunks": [m["overflow_demand"] for m in mem],
+                                               "total": mem[0]["scene_bytes"] + sum(m["slot_bytes"] for m in mem),
+                                               "note": "one scene shared by all frame slots (views); the pool of window-overflow bags "
+                                                       "(96 KiB chunks) follows the demand of the frames before"},
                        "value_sync": None if value_sync is None else round(value_sync, 3),
                        "value_pipelined": None if value_pipe is None else round(value_pipe, 3),
                        "pipelined_frames_in_flight": D if D > 1 else (D_other or None),
@@ -413,10 +437,10 @@ def main():
         if args.dump:
             np.save(args.dump, frame.cpu().numpy())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for t in trs:
+    for t in reversed(trs):  # views first, then the scene
         t.close()
 
 

@@ -23,6 +23,15 @@ static thread_local std::string g_create_err;
         }                                                                                             \
     } while (0)
 
+static void free_slot_state(grt_ctx* c);
+static inline grt_ctx* scene_of(grt_ctx* c) { return c->parent ? c->parent : c; }
+static inline const grt_ctx* scene_of(const grt_ctx* c) { return c->parent ? c->parent : c; }
+// scene calls on a view are refused: the scene belongs to the parent
+#define NOT_A_VIEW(c, what)                                                                           \
+    do {                                                                                              \
+        if ((c)->parent) { (c)->err = what ": this context is a view; change the scene through its parent"; return GRT_ERR_INVALID; } \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // scene kernels
 // ------------------------------------------------------------------------------------------------
@@ -229,6 +238,14 @@ __global__ void k_estimate_costs(const float* __restrict__ pos, uint32_t n, uint
     atomicAdd(&cost[blk * 4u + (((ly % 16u) / 8u) << 1) + ((lx % 16u) / 8u)], 1u);
 }
 
+// FNV-1a over the face indices of the meshes in the order given (grt_update_meshes checks the topology with it)
+static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
+{
+    if (h == 0) h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= f[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -260,12 +277,39 @@ int grt_create(grt_ctx** out, int device)
         (e = hipMalloc(&c->d_counters, kNumCounters * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipStreamCreate(&c->aux_stream)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(&c->d_n_heavy, sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc(&c->d_n_heavy, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_err, sizeof(uint32_t))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_ovf_used, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_ovf, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming)) != hipSuccess) {
         g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
+        free_slot_state(c);
         delete c;
         return GRT_ERR_HIP;
     }
+    *c->h_ovf_used = 0;
     *out = c;
+    return GRT_OK;
+}
+
+// A second frame slot on the SAME scene: its own eye records, scheduling feedback, overflow pool, queues, counters and
+// events, the parent's Gaussians / BVHs / meshes.  What D frames in flight need (bench.py, a double-buffering viewer)
+// without D scene replicas.  Scene calls (upload, build, meshes) go to the parent; the parent must outlive its use by
+// the view's renders (grt_destroy of a parent with live views is deferred until the last of them is destroyed).
+int grt_create_view(grt_ctx* parent, grt_ctx** out)
+{
+    if (!out) return GRT_ERR_INVALID;
+    *out = nullptr;
+    if (!parent || parent->parent) {
+        g_create_err = "grt_create_view: the parent must be a context made by grt_create";
+        return GRT_ERR_INVALID;
+    }
+    grt_ctx* v = nullptr;
+    const int rc = grt_create(&v, parent->device);
+    if (rc != GRT_OK) return rc;
+    v->parent = parent;
+    parent->n_views++;
+    *out = v;
     return GRT_OK;
 }
 
@@ -287,29 +331,52 @@ static void free_meshes(grt_ctx* c)
     free_bvh(&c->mbvh);
 }
 
-void grt_destroy(grt_ctx* c)
+// everything a frame slot owns (a view has nothing else)
+static void free_slot_state(grt_ctx* c)
 {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    free_gaussians(c);
-    free_meshes(c);
-    free_bvh(&c->gbvh);
-    (void)hipFree(c->d_rec);
-    (void)hipFree(c->d_erec);
-    (void)hipFree(c->d_erec_wide);
+    (void)hipFree(c->d_erec); (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
+    (void)hipFree(c->d_err);
+    if (c->h_ovf_used) (void)hipHostFree(c->h_ovf_used);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_ovf) (void)hipEventDestroy(c->ev_ovf);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     (void)hipFree(c->d_n_heavy);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+static void destroy_now(grt_ctx* c)
+{
+    if (!c->parent) {
+        free_gaussians(c);
+        free_meshes(c);
+        free_bvh(&c->gbvh);
+        (void)hipFree(c->d_rec);
+    }
+    free_slot_state(c);
     delete c;
+}
+
+void grt_destroy(grt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize(); // renders of this slot (and, for a scene, of its views) may be in flight on any stream
+    if (c->parent) {
+        grt_ctx* p = c->parent;
+        destroy_now(c);
+        if (--p->n_views == 0 && p->zombie) destroy_now(p);
+        return;
+    }
+    if (c->n_views > 0) { c->zombie = true; return; } // its views still render this scene
+    destroy_now(c);
 }
 
 const char* grt_last_error(const grt_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
@@ -343,12 +410,19 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_LANE_BUDGET) { c->opt_lane_budget = std::max(1, value); }
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
-    else if (option == GRT_OPT_SIZE_CLASSES) { g_size_classes = value ? 1 : 0; }
+    else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
+    else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; }
+    else if (option == GRT_OPT_OVF_ENTRIES) {
+        if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
+        c->opt_ovf_entries = value;
+    }
+    else if (option == GRT_OPT_MAX_ITERS) { c->opt_max_iters = std::max(0, value); }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
         if (value < 1 || value > (int)kLeafMaxPrims) { c->err = "GRT_OPT_LEAF_MAX must be 1..8"; return GRT_ERR_INVALID; }
+        NOT_A_VIEW(c, "GRT_OPT_LEAF_MAX");
         c->opt_leaf_max = value; // takes effect at the next grt_build_bvh / grt_set_meshes
     }
     else { c->err = "grt_set_option: unknown option"; return GRT_ERR_INVALID; }
@@ -366,8 +440,9 @@ int grt_upload_gaussians(grt_ctx* c, const grt_gaussians* g, uint64_t n)
         return GRT_ERR_INVALID;
     }
     if (n >= (1ull << 26)) { c->err = "grt_upload_gaussians: more than 2^26-1 particles (hit keys carry a 26-bit id)"; return GRT_ERR_LIMIT; }
+    NOT_A_VIEW(c, "grt_upload_gaussians");
     CHK(c, hipSetDevice(c->device));
-    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipDeviceSynchronize()); // frames of this scene may be in flight on any stream (caller's, views')
     free_gaussians(c);
     c->h_opacity.assign(g ? g->opacity : nullptr, g ? g->opacity + n : nullptr);
     if (n == 0) return GRT_OK;
@@ -395,7 +470,9 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     if (c) c->scene_epoch++;
     if (!c) return GRT_ERR_INVALID;
     if (!(alpha_min > 0.0f)) { c->err = "grt_build_bvh: alpha_min must be > 0"; return GRT_ERR_INVALID; }
+    NOT_A_VIEW(c, "grt_build_bvh");
     CHK(c, hipSetDevice(c->device));
+    CHK(c, hipDeviceSynchronize());
     c->built = false;
     c->alpha_min = alpha_min;
     const uint32_t n = (uint32_t)c->n;
@@ -421,17 +498,15 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, false, &c->gbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, false, c->opt_size_classes, &c->gbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
         if (c->cap_rec < m) {
             (void)hipFree(c->d_rec);
-            (void)hipFree(c->d_erec);
-            c->d_rec = c->d_erec = nullptr;
+            c->d_rec = nullptr;
             c->cap_rec = 0;
-            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4) + 256)) != hipSuccess ||
-                (e = hipMalloc(&c->d_erec, (size_t)m * sizeof(float4) + 256)) != hipSuccess) {
+            if ((e = hipMalloc(&c->d_rec, (size_t)m * 4 * sizeof(float4) + 256)) != hipSuccess) {
                 c->err = std::string("grt_build_bvh: hipMalloc(rec): ") + hipGetErrorString(e);
                 rc = GRT_ERR_HIP;
             } else c->cap_rec = m;
@@ -459,9 +534,11 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 {
     if (c) c->scene_epoch++;
     if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
+    NOT_A_VIEW(c, "grt_set_meshes");
     CHK(c, hipSetDevice(c->device));
-    CHK(c, hipStreamSynchronize(c->stream));
+    CHK(c, hipDeviceSynchronize());
     free_meshes(c);
+    c->mesh_nv.clear(); c->mesh_nf.clear(); c->faces_hash = 0;
     // Flatten every primitive into one world-space soup; face indices are offset per mesh in the order
     // given (reference: one instance per primitive, instanceId = order of creation,
     // src/GaussianTracer.cpp:592-593; lowest (mesh, face) wins exact-t ties).
@@ -471,6 +548,8 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
         const grt_mesh& m = meshes[k];
         if ((m.nv && (!m.verts || !m.normals)) || (m.nf && !m.faces)) { c->err = "grt_set_meshes: null array"; return GRT_ERR_INVALID; }
         const uint32_t base = (uint32_t)(v.size() / 3);
+        c->mesh_nv.push_back(m.nv); c->mesh_nf.push_back(m.nf);
+        c->faces_hash = faces_hash(c->faces_hash, m.faces, (size_t)m.nf * 3);
         v.insert(v.end(), m.verts, m.verts + (size_t)m.nv * 3);
         nrm.insert(nrm.end(), m.normals, m.normals + (size_t)m.nv * 3);
         for (size_t i = 0; i < (size_t)m.nf * 3; i++) {
@@ -500,7 +579,7 @@ int grt_set_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
     if (rc == GRT_OK) {
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_tri_boxes, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces, nf, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, false, true, &c->mbvh, c->stream, &c->err);
+        rc = build_lbvh(d_lo, d_hi, nf, (uint32_t)c->opt_leaf_max, false, true, 0, &c->mbvh, c->stream, &c->err);
     }
     if (rc == GRT_OK) {
         hipLaunchKernelGGL(k_gather_tris, dim3((nf + 255) / 256), dim3(256), 0, c->stream, d_verts, c->d_faces,
@@ -528,21 +607,36 @@ int grt_update_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 {
     if (c) c->scene_epoch++;
     if (!c || (n_meshes && !meshes)) return GRT_ERR_INVALID;
+    NOT_A_VIEW(c, "grt_update_meshes");
     CHK(c, hipSetDevice(c->device));
-    uint64_t nv = 0, nf = 0;
-    for (uint32_t k = 0; k < n_meshes; k++) { nv += meshes[k].nv; nf += meshes[k].nf; }
-    if (nv != c->n_verts || nf != c->n_faces || nf == 0) {
-        c->err = "grt_update_meshes: vertex / face counts differ from the last grt_set_meshes (call that instead)";
+    // the topology must be the one grt_set_meshes built the tree for: per mesh, not just in total (two meshes that swap
+    // sizes keep the sums), and the same indices (only positions / normals may move)
+    bool same = n_meshes == c->mesh_nv.size() && c->n_faces != 0;
+    for (uint32_t k = 0; same && k < n_meshes; k++) same = meshes[k].nv == c->mesh_nv[k] && meshes[k].nf == c->mesh_nf[k];
+    if (!same) {
+        c->err = "grt_update_meshes: mesh count or per-mesh vertex / face counts differ from the last grt_set_meshes (call that instead)";
+        return GRT_ERR_INVALID;
+    }
+    uint64_t nv = 0, nf = 0, fh = 0;
+    for (uint32_t k = 0; k < n_meshes; k++) {
+        const grt_mesh& m = meshes[k];
+        if ((m.nv && (!m.verts || !m.normals)) || (m.nf && !m.faces)) { c->err = "grt_update_meshes: null array"; return GRT_ERR_INVALID; }
+        fh = faces_hash(fh, m.faces, (size_t)m.nf * 3);
+        nv += m.nv; nf += m.nf;
+    }
+    if (fh != c->faces_hash) {
+        c->err = "grt_update_meshes: face indices differ from the last grt_set_meshes (call that instead)";
         return GRT_ERR_INVALID;
     }
     std::vector<float> v, nrm;
     for (uint32_t k = 0; k < n_meshes; k++) {
         const grt_mesh& m = meshes[k];
-        if (m.nv && (!m.verts || !m.normals)) { c->err = "grt_update_meshes: null array"; return GRT_ERR_INVALID; }
         v.insert(v.end(), m.verts, m.verts + (size_t)m.nv * 3);
         nrm.insert(nrm.end(), m.normals, m.normals + (size_t)m.nv * 3);
     }
-    CHK(c, hipStreamSynchronize(c->stream));
+    // the node boxes, triangles and normals are overwritten in place: no frame may still be reading them, on whatever
+    // stream it was launched (renders are asynchronous on the caller's stream; views have streams of their own)
+    CHK(c, hipDeviceSynchronize());
     float* d_verts = nullptr;
     float4 *d_lo = nullptr, *d_hi = nullptr;
     int rc = GRT_OK;
@@ -579,16 +673,44 @@ int grt_update_meshes(grt_ctx* c, const grt_mesh* meshes, uint32_t n_meshes)
 int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
 {
     if (!c || !o) return GRT_ERR_INVALID;
+    const grt_ctx* sc = scene_of(c);
     memset(o, 0, sizeof(*o));
-    o->n_particles = c->n;
-    o->n_proxies = c->gbvh.n_prims;
-    o->n_nodes = c->gbvh.n_prims ? c->gbvh.n_prims - 1 : 0;
-    o->height = c->gbvh.height;
-    o->mesh_faces = c->n_faces;
-    o->mesh_height = c->mbvh.height;
-    o->build_ms = c->build_ms;
-    o->mesh_update_ms = c->mesh_update_ms;
-    for (int k = 0; k < 3; k++) { o->scene_lo[k] = c->gbvh.lo[k]; o->scene_hi[k] = c->gbvh.hi[k]; }
+    o->n_particles = sc->n;
+    o->n_proxies = sc->gbvh.n_prims;
+    o->n_nodes = sc->gbvh.n_prims ? sc->gbvh.n_prims - 1 : 0;
+    o->height = sc->gbvh.height;
+    o->mesh_faces = sc->n_faces;
+    o->mesh_height = sc->mbvh.height;
+    o->build_ms = sc->build_ms;
+    o->mesh_update_ms = sc->mesh_update_ms;
+    for (int k = 0; k < 3; k++) { o->scene_lo[k] = sc->gbvh.lo[k]; o->scene_hi[k] = sc->gbvh.hi[k]; }
+    return GRT_OK;
+}
+
+// Device memory held: by the scene this context renders (shared by a context and its views) and by this frame slot.
+int grt_get_memory_info(const grt_ctx* c, grt_memory_info* o)
+{
+    if (!c || !o) return GRT_ERR_INVALID;
+    const grt_ctx* sc = scene_of(c);
+    memset(o, 0, sizeof(*o));
+    const uint64_t n = sc->n, m = sc->gbvh.n_prims, nf = sc->n_faces, nv = sc->n_verts;
+    uint64_t b = n * (3 + 3 + 4 + 1 + 48) * 4 + n * 16;                     // raw attributes + color0
+    b += sc->cap_rec * 64;                                                    // proxy records
+    b += sc->gbvh.cap_nodes * 64 + sc->gbvh.cap_order * 4;                    // binary nodes, order
+    if (sc->gbvh.wnodes && m > 1) b += (m - 1) * 128;                         // 4-wide view
+    if (sc->gbvh.qnodes && m > 1) b += (m - 1) * 32ull * kTileWide;           // 8-wide per-child view
+    if (sc->gbvh.pbox) b += m * 32;
+    b += nf * (48 + 12) + nv * 12 + sc->mbvh.cap_nodes * 64 + sc->mbvh.cap_order * 4 + (sc->mbvh.wnodes && nf > 1 ? (nf - 1) * 128 : 0) +
+         (sc->mbvh.level && nf > 1 ? (nf - 1) * 4 : 0);
+    o->scene_bytes = b;
+    uint64_t v = (uint64_t)c->cap_erec * 16 + (uint64_t)c->cap_erec_wide * 64;
+    v += (uint64_t)c->ovf_chunks * kTileOvfChunkBytes;
+    v += (uint64_t)c->cost_cap * 12;
+    v += (uint64_t)c->wf_cap * (48 + 128 + 4 + 64);
+    o->slot_bytes = v;
+    o->overflow_pool_bytes = (uint64_t)c->ovf_chunks * kTileOvfChunkBytes;
+    o->overflow_chunks = c->ovf_chunks;
+    o->overflow_demand = c->ovf_demand;
     return GRT_OK;
 }
 
@@ -598,29 +720,32 @@ int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
 static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 {
     if (!c || !p) return GRT_ERR_INVALID;
-    if (!c->built) { c->err = "render: grt_build_bvh has not been called after the last upload"; return GRT_ERR_INVALID; }
+    const grt_ctx* sc = scene_of(c);
+    if (!sc->built) { c->err = "render: grt_build_bvh has not been called after the last upload"; return GRT_ERR_INVALID; }
     if (p->sh_degree_max > 3) { c->err = "render: sh_degree_max must be 0..3"; return GRT_ERR_INVALID; }
     if (p->type < 0 || p->type > 2) { c->err = "render: type must be MIRROR/NORMAL/GLASS"; return GRT_ERR_INVALID; }
     if (!(p->t_min > 0.0f)) { c->err = "render: t_min must be > 0"; return GRT_ERR_INVALID; }
     memset(a, 0, sizeof(*a));
     a->p = *p;
-    a->rec = c->d_rec;
-    a->nodes = c->gbvh.nodes;
-    a->wnodes = c->gbvh.wnodes;
-    a->qnodes = c->gbvh.qnodes;
-    a->pbox = c->gbvh.pbox;
-    a->root_ref = c->gbvh.root_ref;
-    a->n_prox = c->gbvh.n_prims;
-    a->color0 = c->d_color0;
-    a->sh = c->d_sh;
-    a->mnodes = c->mbvh.nodes;
-    a->tri = c->d_tri;
-    a->mroot = c->n_faces ? c->mbvh.root_ref : kNoRoot;
-    a->n_faces = c->n_faces;
-    a->faces = c->d_faces;
-    a->vnormals = c->d_vnormals;
+    a->rec = sc->d_rec;
+    a->nodes = sc->gbvh.nodes;
+    a->wnodes = sc->gbvh.wnodes;
+    a->qnodes = sc->gbvh.qnodes;
+    a->pbox = sc->gbvh.pbox;
+    a->root_ref = sc->gbvh.root_ref;
+    a->n_prox = sc->gbvh.n_prims;
+    a->color0 = sc->d_color0;
+    a->sh = sc->d_sh;
+    a->mnodes = sc->mbvh.nodes;
+    a->tri = sc->d_tri;
+    a->mroot = sc->n_faces ? sc->mbvh.root_ref : kNoRoot;
+    a->n_faces = sc->n_faces;
+    a->faces = sc->d_faces;
+    a->vnormals = sc->d_vnormals;
     a->counters = c->opt_counters ? c->d_counters : nullptr;
     a->swizzle_chunk = (uint32_t)c->opt_swizzle;
+    a->err_word = c->d_err;
+    a->max_iters = c->opt_max_iters > 0 ? (uint32_t)c->opt_max_iters : kTileMaxItersDefault;
     return GRT_OK;
 }
 
@@ -667,7 +792,8 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_cap = n_units;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
-    if (same && c->order_ready && c->order_epoch == c->scene_epoch && memcmp(&c->order_params, &a.p, sizeof(grt_params)) == 0) {
+    const grt_ctx* sc = scene_of(c);
+    if (same && c->order_ready && c->order_epoch == sc->scene_epoch && memcmp(&c->order_params, &a.p, sizeof(grt_params)) == 0) {
         // the very frame the order was made from (same scene, camera, options): a tile's cost does not depend on the launch
         // order, so this frame would measure the same costs and make the same order again — keep it, collect nothing
         a.order = c->d_order;
@@ -688,13 +814,13 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             a.order = c->d_order;
             if (c->order_split) a.n_heavy = c->d_n_heavy;
         }
-    } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && c->n && (a.mode == 0 || a.mode == 1)) {
+    } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && sc->n && (a.mode == 0 || a.mode == 1)) {
         // no costs of a previous frame with this geometry: order the tiles by the number of particle centres that
         // project into them (dense tiles first), so that the first frame's long tiles do not start last
         CHK(c, hipMemsetAsync(c->d_cost_dil, 0, sizeof(uint32_t) * n_units, s));
-        const uint32_t stride = c->n > 400000 ? 4u : 1u; // original (unsorted) order: every 4th particle is a fair sample
-        const uint32_t ns = ((uint32_t)c->n + stride - 1) / stride;
-        hipLaunchKernelGGL(k_estimate_costs, dim3((ns + 255) / 256), dim3(256), 0, s, c->d_pos, (uint32_t)c->n, stride, a, c->d_cost_dil);
+        const uint32_t stride = sc->n > 400000 ? 4u : 1u; // original (unsorted) order: every 4th particle is a fair sample
+        const uint32_t ns = ((uint32_t)sc->n + stride - 1) / stride;
+        hipLaunchKernelGGL(k_estimate_costs, dim3((ns + 255) / 256), dim3(256), 0, s, sc->d_pos, (uint32_t)sc->n, stride, a, c->d_cost_dil);
         const uint32_t* src = c->d_cost_dil;
         if (a.mode == 0) { // proxies are a few tiles wide: a tile next to a dense one is heavy too
             int rcd = dilate_unit_costs(c->d_cost_dil, c->d_cost, a.nbx, a.nby, 1, s, &c->err);
@@ -718,20 +844,69 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
     return GRT_OK;
 }
 
+// The tile kernel's pool of window-overflow bags: a chunk (kTileOvfChunkBytes = 96 KiB) per tile that overflows.  A tile
+// that finds the pool empty falls back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the
+// default 1 M scene and cost that frame 12 %).  Round 2 held a chunk for EVERY tile of the launch (3.1 GB at 1080p,
+// 12.4 GB at 4K, per frame slot); now the pool follows the DEMAND: the chunk counter of every frame is read back behind
+// it (pinned word, no sync), the pool starts at 3/8 of the tiles (about a third of them overflow on the benchmark scenes)
+// and grows to 1.25 x the largest demand seen + 64 — a frame or two after a camera cut at the latest.  An allocation
+// that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation buffer.
+static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
+{
+    if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
+        c->ovf_demand = std::max(c->ovf_demand, *c->h_ovf_used);
+        c->ovf_pending = false;
+    }
+    if (c->ovf_units != n_tiles) { c->ovf_demand = 0; c->ovf_units = n_tiles; } // another launch geometry: start over
+    uint32_t want;
+    if (c->opt_ovf_chunks != 0) {
+        want = c->opt_ovf_chunks > 0 ? (uint32_t)c->opt_ovf_chunks : 0u;
+        if (want != c->ovf_chunks) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); c->d_ovf = nullptr; c->ovf_chunks = 0; }
+    } else {
+        const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
+        const uint32_t first = n_tiles - n_tiles / 2u - n_tiles / 8u + 64u; // 3/8 of the tiles
+        const uint32_t seen = c->ovf_demand + c->ovf_demand / 4u + 64u;
+        want = std::min(std::min(cap, std::max(n_tiles, 1u)), std::max(c->ovf_demand ? seen : first, 64u));
+    }
+    if (c->ovf_chunks < want) {
+        if (c->d_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); } // a frame in flight may still use it
+        c->d_ovf = nullptr;
+        c->ovf_chunks = 0;
+        for (uint32_t n = want; n >= 1u; n /= 2u) {
+            if (hipMalloc(&c->d_ovf, (size_t)n * kTileOvfChunkBytes) == hipSuccess) { c->ovf_chunks = n; break; }
+            (void)hipGetLastError(); // out of memory is not an error of the frame: a smaller pool, or none
+            c->d_ovf = nullptr;
+            if (c->opt_ovf_chunks > 0) break;
+        }
+    }
+    return GRT_OK;
+}
+
 static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
 {
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    grt_ctx* sc = scene_of(c);
     CHK(c, hipSetDevice(c->device));
+    if (c->seen_epoch != sc->scene_epoch) { // the scene changed under this slot (a view learns of it here)
+        c->erec_valid = false;
+        c->cost_valid = false;
+        c->order_ready = false;
+        c->seen_epoch = sc->scene_epoch;
+    }
+    // the zeroing / ordering queued behind the last frame ran on THAT frame's stream: a launch on another stream waits
+    // for it (else it could start before its counters are reset — two tiles taking the same overflow chunk)
+    if (c->tail_pending && c->tail_stream != s) CHK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
+    c->tail_pending = false;
     {
         // the streaming kernel runs one 8x8 tile (one wave) per workgroup and is scheduled per tile; the other
         // kernels per 16x16 block (same test as launch_render)
-        const uint32_t h = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
+        const uint32_t h = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
         const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
         int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks);
         if (rcf != GRT_OK) return rcf;
     }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
-    const uint32_t depth = std::max(std::max(c->gbvh.height, c->n_faces ? c->mbvh.height : 0u), 1u);
+    const uint32_t depth = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
     a.prec = nullptr; a.queue = nullptr; a.qcount = nullptr;
     a.queue_in = nullptr; a.qcount_in = nullptr; a.queue_alt = nullptr;
     a.heavy = nullptr; a.hcount = nullptr; a.hnext = nullptr; a.fqueue = nullptr; a.fcount = nullptr;
@@ -743,7 +918,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.single_own_mesh = 0;
     a.single_look = (float)c->opt_single_look / 1024.0f;
     a.single_band = (float)c->opt_single_band / 1024.0f;
-    if (c->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
+    if (sc->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
         const size_t need = (size_t)a.n_blocks * 256;
         if (c->wf_cap < need) {
             (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
@@ -761,13 +936,12 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.queue_alt = c->d_queue + c->wf_cap * 4;
         a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
-    CHK(c, hipEventRecord(c->ev0, s));
-    a.erec = nullptr;
-    if (a.mode != 2 && c->gbvh.n_prims && c->d_erec && c->opt_kernel != 1 && c->opt_kernel != 2) {
-        // streaming kernel on camera rays: refresh the eye records when the eye moved (part of the timed frame)
-        const uint32_t m = c->gbvh.n_prims;
-        const bool wide = uses_tile_kernel(c->opt_kernel, a.mode, depth, c->built_leaf_max);
-        if (wide && c->cap_erec_wide < m) {
+    const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max);
+    // allocations first (they may synchronise): eye records of this slot, overflow pool
+    const uint32_t m = sc->gbvh.n_prims;
+    const bool want_erec = a.mode != 2 && m && c->opt_kernel != 1 && c->opt_kernel != 2;
+    if (want_erec) {
+        if (tile_kernel && c->cap_erec_wide < m) {
             (void)hipFree(c->d_erec_wide);
             c->d_erec_wide = nullptr;
             c->cap_erec_wide = 0;
@@ -775,12 +949,33 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
             c->cap_erec_wide = m;
             c->erec_valid = false;
         }
+        if (!tile_kernel && c->cap_erec < m) {
+            (void)hipFree(c->d_erec);
+            c->d_erec = nullptr;
+            c->cap_erec = 0;
+            CHK(c, hipMalloc(&c->d_erec, (size_t)m * sizeof(float4) + 256));
+            c->cap_erec = m;
+            c->erec_valid = false;
+        }
+    }
+    a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
+    a.ovf_entries = c->opt_ovf_entries > 0 ? (uint32_t)c->opt_ovf_entries : kTileOvfEntries;
+    if (tile_kernel) {
+        int rco = size_overflow_pool(c, a.n_blocks * 4u);
+        if (rco != GRT_OK) return rco;
+        if (!c->d_ovf_next) CHK(c, hipMalloc(&c->d_ovf_next, sizeof(uint32_t)));
+    }
+    CHK(c, hipEventRecord(c->ev0, s));
+    a.erec = nullptr;
+    if (want_erec) {
+        // wave-per-tile kernels on camera rays: refresh the eye records when the eye moved (part of the timed frame)
+        const bool wide = tile_kernel;
         if (!c->erec_valid || c->erec_is_wide != wide || memcmp(c->erec_eye, a.p.eye, sizeof(c->erec_eye)) != 0) {
             if (wide)
-                hipLaunchKernelGGL(k_eye_records_wide, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0],
+                hipLaunchKernelGGL(k_eye_records_wide, dim3((m + 255) / 256), dim3(256), 0, s, sc->d_rec, m, a.p.eye[0],
                                    a.p.eye[1], a.p.eye[2], c->d_erec_wide);
             else
-                hipLaunchKernelGGL(k_eye_records, dim3((m + 255) / 256), dim3(256), 0, s, c->d_rec, m, a.p.eye[0], a.p.eye[1],
+                hipLaunchKernelGGL(k_eye_records, dim3((m + 255) / 256), dim3(256), 0, s, sc->d_rec, m, a.p.eye[0], a.p.eye[1],
                                    a.p.eye[2], c->d_erec);
             memcpy(c->erec_eye, a.p.eye, sizeof(c->erec_eye));
             c->erec_valid = true;
@@ -792,30 +987,13 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     aux.aux = c->aux_stream; aux.fork = c->ev_fork; aux.join = c->ev_join;
     aux.heavy_cap = a.n_heavy ? std::max(1u, a.n_units / (uint32_t)c->opt_heavy_cap_div) : 0u; // in scheduling units
     aux.force_big = c->opt_kernel == 4;
-    const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, c->built_leaf_max);
     if (tile_kernel) { a.n_heavy = nullptr; aux.heavy_cap = 0; } // no big-window split on the tile kernel
     a.tile_ready_min = (uint32_t)c->opt_tile_ready;
     a.tile_band = (float)c->opt_tile_band / 1024.0f;
     a.tile_look = (float)c->opt_tile_look / 1024.0f;
     a.tile_reserve = (uint32_t)c->opt_tile_reserve;
     a.tile_prio_div = (uint32_t)c->opt_tile_prio;
-    a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
     if (tile_kernel) {
-        // pool of window-overflow bags: a chunk (kTileOvfChunkBytes = 96 KiB) per tile that overflows, and one for EVERY
-        // tile of the launch (3.1 GB for a 1080p frame; only the chunks that are taken are ever touched): a tile that
-        // finds the pool empty falls back to another pass — never wrong, but on the default 1 M scene a pool for a
-        // quarter of the tiles ran dry and cost the frame 12 %
-        // (capped at 16 GiB: a 4K frame takes 12.4 GB; beyond the cap the tiles that find the pool empty go again)
-        const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
-        const uint32_t want = std::min(cap, std::max(256u, a.n_blocks * 4u));
-        if (c->ovf_chunks < want) {
-            (void)hipFree(c->d_ovf);
-            c->d_ovf = nullptr;
-            c->ovf_chunks = 0;
-            CHK(c, hipMalloc(&c->d_ovf, (size_t)want * kTileOvfChunkBytes));
-            c->ovf_chunks = want;
-        }
-        if (!c->d_ovf_next) CHK(c, hipMalloc(&c->d_ovf_next, sizeof(uint32_t)));
         if (!c->ovf_zeroed) CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
         c->ovf_zeroed = false;
         a.ovf_pool = c->d_ovf; a.ovf_next = c->d_ovf_next; a.ovf_chunks = c->ovf_chunks;
@@ -823,17 +1001,29 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
     c->have_timing = (rc == GRT_OK);
-    if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order, behind this frame (not in its timing)
+    // ---- behind the frame, outside its timing (grt_last_kernel_ms brackets ev0..ev1; the feedback kernels below are
+    //      ~60 us per frame under a moving camera and are what `frame ms - kernel ms` of bench.py's orbit leg shows) ----
+    bool tail = false;
+    if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order
         if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
             c->order_ready = true;
             c->order_valid = true;
             c->order_params = a.p;
-            c->order_epoch = c->scene_epoch;
+            c->order_epoch = sc->scene_epoch;
             // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)
             if (hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_units, s) == hipSuccess) c->cost_zeroed = true;
+            tail = true;
         }
     }
-    if (rc == GRT_OK && a.ovf_next && hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s) == hipSuccess) c->ovf_zeroed = true;
+    if (rc == GRT_OK && a.ovf_next) {
+        // the chunks this frame asked for -> pinned host word (sizes the pool of the frames to come), then the reset
+        if (!c->ovf_pending && hipMemcpyAsync(c->h_ovf_used, c->d_ovf_next, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipEventRecord(c->ev_ovf, s) == hipSuccess)
+            c->ovf_pending = true;
+        if (hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s) == hipSuccess) c->ovf_zeroed = true;
+        tail = true;
+    }
+    if (tail && hipEventRecord(c->ev_tail, s) == hipSuccess) { c->tail_pending = true; c->tail_stream = s; }
     return rc;
 }
 
@@ -919,13 +1109,31 @@ int grt_render_rays(grt_ctx* c, const grt_params* p, const float* d_rays, uint64
     return do_launch(c, a, stream);
 }
 
+// The sticky device error word (RenderArgs::err_word): a wave that had to give up on a ray — watchdog, depth-first stack
+// guard, two passes without progress — ORs its reason in, in EVERY kernel variant (counters on or off).  Read (and
+// cleared) at the synchronising entry points; the reference turns traversal trouble into exceptions the same way
+// (OptiX exception flags, src/GaussianTracer.cpp:114-119; src/Exception.h:31-80).  The stream must be idle.
+static int check_device_error(grt_ctx* c)
+{
+    uint32_t w = 0;
+    CHK(c, hipMemcpy(&w, c->d_err, sizeof(w), hipMemcpyDeviceToHost));
+    if (!w) return GRT_OK;
+    CHK(c, hipMemset(c->d_err, 0, sizeof(w)));
+    c->err = std::string("render: a wave gave up on live rays (pixels are missing hits):") +
+             ((w & kErrWatchdog) ? " step watchdog expired;" : "") + ((w & kErrStack) ? " depth-first overflow stack full;" : "") +
+             ((w & kErrStall) ? " two passes without progress;" : "");
+    return GRT_ERR_LIMIT;
+}
+
 int grt_sync(grt_ctx* c)
 {
     if (!c) return GRT_ERR_INVALID;
     CHK(c, hipSetDevice(c->device));
     CHK(c, hipStreamSynchronize(c->stream));
+    // (renders go to the caller's stream: the last frame is finished once the event recorded behind its kernels is)
+    if (c->have_timing) CHK(c, hipEventSynchronize(c->ev1));
     CHK(c, hipGetLastError());
-    return GRT_OK;
+    return check_device_error(c);
 }
 
 int grt_get_counters(grt_ctx* c, grt_counters* out)
@@ -937,7 +1145,7 @@ int grt_get_counters(grt_ctx* c, grt_counters* out)
     CHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->rays = h[0]; out->segments = h[1]; out->hit_evals = h[2]; out->rounds = h[3];
     out->node_visits = h[4]; out->proxy_tests = h[5]; out->rec_fetches = h[6]; out->stall_exits = h[7];
-    return GRT_OK;
+    return check_device_error(c);
 }
 
 int grt_last_kernel_ms(grt_ctx* c, float* ms)

@@ -26,8 +26,6 @@
 
 namespace grt {
 
-int g_size_classes = 1; // Gaussian BVH: size classes in the Morton key (GRT_OPT_SIZE_CLASSES; testing knob)
-
 #define HIPCHK(x)                                                                                     \
     do {                                                                                              \
         hipError_t e_ = (x);                                                                          \
@@ -54,7 +52,10 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o)
 #endif
 }
 
-// bounds[0..2] = min centroid (ordered uint), [3..5] = max, [6] = valid count, [7] = sum of the box diagonals (float)
+// bounds[0..2] = min centroid (ordered uint), [3..5] = max, [6] = valid count, [7] = sum of the box diagonals (float),
+// [8 + b] = workgroup b's part of that sum.  The sum decides the size classes (k_morton) and with them the Morton order
+// and the tree, so it is reduced in a FIXED order (lanes by shuffles, waves and workgroups sequentially): the same
+// scene gives the same BVH on every run and every rank (a float atomicAdd across waves did not).
 __global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n,
                                uint32_t* __restrict__ bounds)
 {
@@ -81,27 +82,38 @@ __global__ void k_scene_bounds(const float4* __restrict__ lo, const float4* __re
         cnt += (uint32_t)__shfl_xor((int)cnt, off);
         dsum += __shfl_xor(dsum, off);
     }
-    if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<float*>(&bounds[7]), dsum);
     // one set of atomics per WORKGROUP (the waves meet in LDS first): 7 x 256 atomics instead of 7 x 8192 on one line
     __shared__ uint32_t red[4][7];
+    __shared__ float dred[4];
     const uint32_t wv = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 3; k++) { red[wv][k] = mn[k]; red[wv][3 + k] = mx[k]; }
         red[wv][6] = cnt;
+        dred[wv] = dsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t nw = (blockDim.x + 63u) >> 6;
+        float ds = dred[0];
         for (uint32_t w = 1; w < nw; w++) {
             for (int k = 0; k < 3; k++) { red[0][k] = min(red[0][k], red[w][k]); red[0][3 + k] = max(red[0][3 + k], red[w][3 + k]); }
             red[0][6] += red[w][6];
+            ds += dred[w];
         }
+        bounds[8 + blockIdx.x] = __float_as_uint(ds);
         for (int k = 0; k < 3; k++) {
             atomicMin(&bounds[k], red[0][k]);
             atomicMax(&bounds[3 + k], red[0][3 + k]);
         }
         atomicAdd(&bounds[6], red[0][6]);
     }
+}
+
+__global__ void k_scene_bounds_finish(uint32_t* __restrict__ bounds, uint32_t n_parts)
+{
+    float s = 0.0f;
+    for (uint32_t b = 0; b < n_parts; b++) s += __uint_as_float(bounds[8 + b]);
+    bounds[7] = __float_as_uint(s);
 }
 
 __device__ __forceinline__ uint64_t expand21(uint32_t v)
@@ -536,7 +548,7 @@ fail:
 }
 
 int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
-               DevBvh* out, hipStream_t stream, std::string* err)
+               int size_classes, DevBvh* out, hipStream_t stream, std::string* err)
 {
     uint2* d_range = nullptr;
     uint32_t* d_bounds = nullptr;
@@ -559,7 +571,7 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         return GRT_ERR_LIMIT;
     }
 
-    HIPCHK(hipMalloc(&d_bounds, 8 * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&d_bounds, (8 + 256) * sizeof(uint32_t)));
     {
         const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(d_bounds, init, sizeof(init), hipMemcpyHostToDevice, stream));
@@ -577,8 +589,9 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     {
         const int grid = (int)std::min<uint32_t>((n_in + B - 1) / B, 256u);
         hipLaunchKernelGGL(k_scene_bounds, dim3(grid), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds);
+        hipLaunchKernelGGL(k_scene_bounds_finish, dim3(1), dim3(1), 0, stream, d_bounds, (uint32_t)grid);
         hipLaunchKernelGGL(k_morton, dim3((n_in + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds, d_keys,
-                           d_vals, want_quad ? g_size_classes : 0);
+                           d_vals, want_quad ? size_classes : 0);
     }
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
                                      stream));

@@ -53,13 +53,13 @@ struct DevBvh {
 // Returns GRT_OK or an error code (message in *err).
 // want_quad: also build the per-child layout (qnodes, pbox) the tile kernel traverses.
 // keep_levels: keep the per-node refit order so that refit_lbvh can re-fit the boxes of the SAME hierarchy later.
+// size_classes: Gaussian BVH only (GRT_OPT_SIZE_CLASSES of the context that builds).
 int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
-               DevBvh* out, hipStream_t stream, std::string* err);
+               int size_classes, DevBvh* out, hipStream_t stream, std::string* err);
 // Re-fit every reachable node's boxes to new primitive boxes (same primitives, same order, same hierarchy): what a
 // gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
 int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
-extern int g_size_classes;
 
 // Everything the render kernel reads, passed by value.
 struct RenderArgs {
@@ -111,6 +111,11 @@ struct RenderArgs {
     float4* ovf_pool;        // window overflow bags: [chunk][entry][lane] x 16 B, one chunk per tile that overflows
     uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
     uint32_t ovf_chunks;     // chunks in the pool
+    uint32_t ovf_entries;    // per-lane capacity of a bag actually used (<= kTileOvfEntries; smaller only in tests)
+    // always-on failure signal: a wave that has to give up on a ray (watchdog, stack guard, two passes without progress)
+    // ORs its reason into this device word, whatever the kernel variant; grt_sync / grt_get_counters report it
+    uint32_t* err_word;
+    uint32_t max_iters;      // watchdog of the tile kernel: steps one tile may take (test override: GRT_OPT_MAX_ITERS)
     // wavefront pipeline for mesh frames (grt_render.hip: k_primary_mesh / k_bounce, grt_render_stream.hip MESH=true)
     float4* prec;      // [n_blocks*256][3] mesh-hit records: of the pixels (stage 1), later of the queue entries (stage 3)
     float4* queue;     // [n_blocks*256][4] continuation rays this launch WRITES: 64-entry chunks, one per 8x8 tile that has
@@ -146,6 +151,13 @@ int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t
                          std::string* err);
 int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err);
 constexpr int kNumCounters = 8;
+// bits of RenderArgs::err_word
+constexpr uint32_t kErrWatchdog = 1u, kErrStack = 2u, kErrStall = 4u;
+constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
+constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
+// The stack receives the batch that overflowed (<= 64) plus up to kTileWide - 1 siblings per 8-wide level below it
+// (three binary levels per wide level): the launcher sends taller trees to the streaming kernel.
+inline bool tile_stack_fits(uint32_t height) { return ((height + 2u) / 3u) * (kTileWide - 1u) + 64u <= kTileStack; }
 constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
 // round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the retry queue, [2R+2 .. 3R+1] the draw
@@ -169,7 +181,8 @@ inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
 // the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
 inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max)
 {
-    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4;
+    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4 &&
+           tile_stack_fits(stack_depth);
 }
 // per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)
 int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,
@@ -180,7 +193,14 @@ int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, u
 
 }  // namespace grt
 
+// A context owns a SCENE (Gaussians, BVHs, records, meshes) and the per-frame state of ONE frame slot (eye records,
+// scheduling feedback, overflow pool, wavefront queues, counters, events).  A VIEW (grt_create_view) is a context with
+// frame-slot state of its own that renders its parent's scene: D frames in flight share one scene replica.
 struct grt_ctx {
+    grt_ctx* parent = nullptr; // view: the context whose scene this one renders
+    int n_views = 0;           // live views of this context
+    bool zombie = false;       // destroyed while views were alive: freed with the last of them
+    uint64_t seen_epoch = 0;   // scene_epoch of the scene at this slot's last launch
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -189,9 +209,22 @@ struct grt_ctx {
     int opt_leaf_max = 4;
     int opt_swizzle = 2;
     int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24, opt_tile_prio = 0; // band / look in 1/1024
+    int opt_size_classes = 1;
     float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags
     uint32_t* d_ovf_next = nullptr;
     uint32_t ovf_chunks = 0;
+    int opt_ovf_chunks = 0;       // 0 = sized from demand; > 0: exactly this many chunks (testing); < 0: no pool at all
+    int opt_ovf_entries = 0;      // 0 = kTileOvfEntries; testing: a smaller per-lane bag
+    int opt_max_iters = 0;        // 0 = kTileMaxItersDefault; testing: a tiny watchdog
+    uint32_t* h_ovf_used = nullptr; // pinned: chunks the last finished frame asked for (read back behind every frame)
+    hipEvent_t ev_ovf = nullptr;
+    bool ovf_pending = false;
+    uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
+    uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
+    uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)
+    hipStream_t tail_stream = nullptr; // stream the post-frame work (next order, zeroing) was queued on
+    hipEvent_t ev_tail = nullptr;
+    bool tail_pending = false;
     int built_leaf_max = 4; // leaf_max of the current Gaussian BVH (the tile kernel expands ranges of <= 4)
     // uploaded attributes (original order)
     uint64_t n = 0;
@@ -204,7 +237,7 @@ struct grt_ctx {
     float4* d_rec = nullptr;
     float4* d_erec = nullptr;   // per-eye records of the streaming kernel (grt_api.hip: k_eye_records)
     float4* d_erec_wide = nullptr; // 64-B eye records of the tile kernel (k_eye_records_wide)
-    size_t cap_erec_wide = 0;
+    size_t cap_erec_wide = 0, cap_erec = 0;
     bool erec_is_wide = false;
     float erec_eye[3] = {0, 0, 0};
     bool erec_valid = false;
@@ -218,6 +251,8 @@ struct grt_ctx {
     uint32_t* d_faces = nullptr;
     float* d_vnormals = nullptr;
     uint32_t n_faces = 0, n_verts = 0;
+    std::vector<uint32_t> mesh_nv, mesh_nf; // per mesh, as given to the last grt_set_meshes
+    uint64_t faces_hash = 0;
     // instrumentation
     unsigned long long* d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -50,11 +50,12 @@ constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of Rend
 constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kernel
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
 constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
-constexpr uint32_t kMaxIters = 1u << 21; // steps of one tile before the watchdog gives up (a heavy C3 tile takes ~2000)
-constexpr uint32_t kStack = 288u; // depth-first overflow stack (only when the LDS bag is full too; guarded).  LDS per wave
-                                  // must stay <= 10 KB: 10304 B gave 15 waves per CU instead of 16 and cost 4 %
-constexpr uint32_t kKeep = 40u;
-constexpr uint32_t kOvf = kTileOvfEntries; // per-lane capacity of the window's overflow bag (entries of 16 B, in global memory)  // frontier entries kept in registers by a rebalance (the nearest ones)
+constexpr uint32_t kStack = kTileStack; // depth-first overflow stack (only when the LDS bag is full too; guarded; the launcher
+                                  // admits only trees it can hold: tile_stack_fits).  LDS per wave must stay <= 10 KB:
+                                  // 10304 B gave 15 waves per CU instead of 16 and cost 4 %
+constexpr uint32_t kKeep = 40u; // frontier entries kept in registers by a rebalance (the nearest ones)
+constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a lane's column of an overflow chunk holds; the
+                                           // capacity in use is a.ovf_entries (<= kOvf; smaller only in tests)
 
 #ifndef GRT_TILE_WAVES
 #define GRT_TILE_WAVES 4
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
-    __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + 3 siblings per level
-                                 // below it (<= 3 * 62 for the tree heights the launcher sends here)
+    __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + kTileWide - 1 siblings
+                                 // per wide level below it (tile_stack_fits, grt_internal.h)
     for (uint32_t unit_s = rank;;) { // (one trip; MODE 2: the waves draw the rays of the heavy list from a counter, so
                                      //  that a wave stuck with a long ray does not hold a share of the others back)
     if (SINGLE) {
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                 // any later pass (a lane came back: its cut-off did fall short).  Behind a moving front the arrivals are
                 // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
-                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb >= kOvf - GRT_PRUNE_ROOM);
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + GRT_PRUNE_ROOM >= a.ovf_entries);
                     if (wave_any(pr_)) { // wave-uniform, rare
                         bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
                         lim_dirty = true;
@@ -768,8 +769,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                     }
                 }
                 if (done) break;
-                if (++iters > kMaxIters) { // watchdog: never reached by design; a counted, visible failure beats a hung GPU
+                if (++iters > a.max_iters) { // watchdog: never reached by design; a reported failure beats a hung GPU
                     c.stall_exits += alive ? 1u : 0u;
+                    if (lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrWatchdog);
                     watchdog = true;
                     break;
                 }
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                                     chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); // pool exhausted: drop for good
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < kOvf) && (dk < lost);
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
                                     a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
@@ -1036,6 +1038,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                     } else {
                         if (nc > nf && dsp + (nc - nf) > kStack) { // cannot happen for the tree heights the launcher admits
                             c.stall_exits += alive ? 1u : 0u;
+                            if (lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrStack);
                             watchdog = true;
                             break;
                         }
@@ -1060,6 +1063,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
             stalls = parked ? stalls : (progressed ? 0u : stalls + 1u);
             const bool again = alive && (lost != kKeyInvalid);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
+            if (wave_any(again && stalls >= 2u) && lane == 0u) atomicOr(a.err_word, kErrStall); // (never seen: rare by construction)
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
         if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[unit], iters);

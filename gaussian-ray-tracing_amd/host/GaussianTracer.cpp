@@ -86,6 +86,9 @@ void GaussianTracer::render(CUDAOutputBuffer& output_buffer) // src/GaussianTrac
     check(grt_render(m_ctx, &p, reinterpret_cast<uint8_t*>(result), nullptr, 0, 0, params.width, params.height, stream), "grt_render");
     output_buffer.unmap();
     hipglue::streamSync(stream); // CUDA_SYNC_CHECK, :537
+    // the frame is done: a wave that had to give up on live rays (watchdog, stack guard, stalled passes) left its reason
+    // in the context's sticky error word — thrown here, as OptiX exceptions are in the reference (:114-119, Exception.h:31-80)
+    check(grt_sync(m_ctx), "render");
 }
 
 void GaussianTracer::updateCamera(Camera& camera, bool& camera_changed) // src/GaussianTracer.cpp:540-551

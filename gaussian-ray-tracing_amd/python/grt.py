@@ -39,6 +39,11 @@ class BvhInfo(C.Structure):
                 ("build_ms", C.c_float), ("mesh_update_ms", C.c_float), ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3)]
 
 
+class MemoryInfo(C.Structure):
+    _fields_ = [("scene_bytes", C.c_uint64), ("slot_bytes", C.c_uint64), ("overflow_pool_bytes", C.c_uint64),
+                ("overflow_chunks", C.c_uint32), ("overflow_demand", C.c_uint32)]
+
+
 class Gaussians(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("pos", "scale", "quat", "opacity", "sh")]
 
@@ -52,10 +57,12 @@ MIRROR, NORMAL, GLASS = 0, 1, 2
 OPT_COUNTERS, OPT_KERNEL, OPT_LEAF_MAX, OPT_SWIZZLE, OPT_FEEDBACK = 1, 2, 3, 4, 5
 OPT_TILE_READY_MIN, OPT_TILE_BAND, OPT_TILE_LOOKAHEAD, OPT_TILE_RESERVE, OPT_TILE_PRIO_DIV, OPT_COST_RADIUS, OPT_SIZE_CLASSES, OPT_COLD_ESTIMATE = 8, 9, 10, 11, 12, 13, 14, 15
 OPT_BUNDLE_ROUNDS, OPT_BUNDLE_BUDGET, OPT_SINGLE_LOOKAHEAD, OPT_SINGLE_BAND, OPT_LANE_BUDGET = 16, 17, 18, 19, 20
+OPT_OVF_CHUNKS, OPT_OVF_ENTRIES, OPT_MAX_ITERS = 21, 22, 23
+ERR_LIMIT = -5
 KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERNEL_TILE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
-    "grt_create", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
+    "grt_create", "grt_create_view", "grt_get_memory_info", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
     "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_assemble_tiles", "grt_render_rays", "grt_sync",
     "grt_get_counters", "grt_last_kernel_ms", "grt_host_activate", "grt_host_uvw_frame", "grt_host_synth_scene",
     "grt_host_ply_count", "grt_host_ply_read", "grt_host_ply_write", "grt_host_last_error",
@@ -83,6 +90,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, u32, u64, fl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float
         L.grt_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.grt_create_view.argtypes = [vp, C.POINTER(vp)]
+        L.grt_get_memory_info.argtypes = [vp, C.POINTER(MemoryInfo)]
         L.grt_destroy.argtypes = [vp]
         L.grt_last_error.restype = C.c_char_p
         L.grt_last_error.argtypes = [vp]
@@ -97,6 +106,7 @@ def lib():
         L.grt_assemble_tiles.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
         L.grt_render_rays.argtypes = [vp, C.POINTER(Params), vp, u64, vp, vp]
         L.grt_sync.argtypes = [vp]
+        L.grt_sync.restype = C.c_int
         L.grt_get_counters.argtypes = [vp, C.POINTER(Counters)]
         L.grt_last_kernel_ms.argtypes = [vp, C.POINTER(fl)]
         L.grt_host_activate.argtypes = [u64] + [vp] * 11
@@ -269,20 +279,37 @@ def plane_mesh(center, width=0.3, height=0.5):
 class Tracer:
     """One context per GPU (mirrors class GaussianTracer, src/GaussianTracer.h:27-111)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, scene=None):
+        """scene = another Tracer: this one is a VIEW of it (grt_create_view) — a frame slot of its own on that
+        Tracer's Gaussians / BVHs / meshes."""
         import torch
         if not torch.cuda.is_available():
             raise GrtError("no GPU visible: libgrt_hip has no CPU fallback")
         self._torch = torch
-        self.device = device
+        self.device = device if scene is None else scene.device
         self._h = C.c_void_p()
-        rc = lib().grt_create(C.byref(self._h), device)
+        self._scene = scene  # keeps the parent alive as long as the view
+        rc = lib().grt_create(C.byref(self._h), device) if scene is None else lib().grt_create_view(scene._h, C.byref(self._h))
         if rc != 0:
             raise GrtError(f"grt_create failed ({rc}): {lib().grt_last_error(None).decode()}")
 
+    def view(self):
+        return Tracer(scene=self)
+
     def _check(self, rc):
         if rc != 0:
-            raise GrtError(f"grt error {rc}: {lib().grt_last_error(self._h).decode()}")
+            e = GrtError(f"grt error {rc}: {lib().grt_last_error(self._h).decode()}")
+            e.code = rc
+            raise e
+
+    def memory_info(self):
+        o = MemoryInfo()
+        self._check(lib().grt_get_memory_info(self._h, C.byref(o)))
+        return {n: int(getattr(o, n)) for n, _ in o._fields_}
+
+    def check(self):
+        """grt_sync: waits for the last frame and raises (code ERR_LIMIT) when a wave gave up on live rays."""
+        self._check(lib().grt_sync(self._h))
 
     def set_option(self, opt, val):
         self._check(lib().grt_set_option(self._h, opt, val))

@@ -2,7 +2,7 @@
 // (src/main.cpp:9-131) on a display-less MI355X: same flags -p/--ply, --width, --height and the same
 // defaults (src/main.cpp:62-66: ../data/train.ply, 1280x720), the same call sequence
 // (tracer.setSize -> initializeOptix -> camera init (src/gui.cpp:50-67) -> updateCamera -> render),
-// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png --bench N.
+// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png|frame.npy --bench N.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -72,11 +72,26 @@ static void write_png(const std::string& path, const unsigned char* rgb_top_down
     chunk("IEND", {});
 }
 
+// NumPy .npy v1.0: uint8 [h][w][3], C order — the buffer as the renderer wrote it (row 0 first), what numpy.load returns
+static void write_npy(const std::string& path, const unsigned char* rgb, unsigned int w, unsigned int h)
+{
+    std::string hdr = "{'descr': '|u1', 'fortran_order': False, 'shape': (" + std::to_string(h) + ", " + std::to_string(w) + ", 3), }";
+    while ((10 + hdr.size() + 1) % 64) hdr.push_back(' ');
+    hdr.push_back('\n');
+    std::ofstream f(path, std::ios::binary);
+    const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    f.write(reinterpret_cast<const char*>(magic), 8);
+    const unsigned char len[2] = {(unsigned char)(hdr.size() & 0xFF), (unsigned char)(hdr.size() >> 8)};
+    f.write(reinterpret_cast<const char*>(len), 2);
+    f.write(hdr.data(), (std::streamsize)hdr.size());
+    f.write(reinterpret_cast<const char*>(rgb), (std::streamsize)((size_t)w * h * 3));
+}
+
 static void usage()
 {
     std::puts("usage: grt_render [-p|--ply scene.ply] [--width W] [--height H] [--fisheye] [--type mirror|normal|glass]\n"
               "                  [--sh-degree 0..3] [--plane] [--sphere] [--obj mesh.obj] [--bounces N]\n"
-              "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png] [--raw frame.rgb]\n"
+              "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png|frame.npy] [--raw frame.rgb]\n"
               "                  [--move dx dy dz] [--bench N]");
 }
 
@@ -165,7 +180,10 @@ int main(int argc, char** argv)
         if (!out.empty()) {
             // what the viewer's window shows: buffer row 0 at the bottom (src/Display.cpp:13,184)
             const std::vector<unsigned char> top_down = GLDisplay::windowImage(output_buffer);
-            if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
+            if (out.size() > 4 && out.compare(out.size() - 4, 4, ".npy") == 0) {
+                // an array for parity checks, not a picture: the renderer's own row order (shaders/tracer.cuh:487)
+                write_npy(out, reinterpret_cast<const unsigned char*>(output_buffer.getHostPointer()), width, height);
+            } else if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
                 write_png(out, top_down.data(), width, height);
             } else {
                 std::ofstream f(out, std::ios::binary);

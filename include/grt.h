@@ -10,6 +10,8 @@
  *
  * What each entry point replaces in the reference:
  *   grt_create / grt_destroy      createContext..createSBT + dtor          src/GaussianTracer.cpp:85-295, 54-70
+ *   grt_create_view               (new) a second frame slot on the same scene: what D frames in flight need, where the
+ *                                 reference has one stream and one frame at a time (src/GaussianTracer.cpp:504,537)
  *   grt_upload_gaussians          particle upload in initializeParams      src/GaussianTracer.cpp:491-502
  *   grt_build_bvh                 createGaussianParticlesBVH/createGAS/    src/GaussianTracer.cpp:297-317,
  *                                 buildAccelationStructure (OptiX, closed)   319-399, 422-473
@@ -101,8 +103,10 @@ typedef struct {
     uint64_t rec_fetches; /* BVH node / proxy record bytes fetched by the wave-cooperative kernels, in 16-B units, at
                              the granularity they are loaded (one scalar load per wave): streaming kernel — a 4-wide
                              node = 8, a proxy record + its eye record = 5; round-based wave kernel — a 64-B record = 4 */
-    uint64_t stall_exits; /* rays the streaming kernel gave up on with transmittance left because two passes in a row
-                             composited nothing (must be 0: a non-zero value means a pixel is missing hits) */
+    uint64_t stall_exits; /* rays a wave-per-tile kernel (tile or streaming) gave up on with transmittance left: two passes in
+                             a row composited nothing, or the step watchdog / stack guard fired (must be 0: a non-zero value
+                             means a pixel is missing hits).  Counted with GRT_OPT_COUNTERS; the same events set the sticky
+                             error word in EVERY kernel variant: grt_sync / grt_get_counters then return GRT_ERR_LIMIT */
 } grt_counters;
 
 typedef struct {
@@ -116,6 +120,14 @@ typedef struct {
     float mesh_update_ms;   /* device time of the last grt_set_meshes (build) / grt_update_meshes (refit) */
     float scene_lo[3], scene_hi[3];
 } grt_bvh_info;
+
+typedef struct {
+    uint64_t scene_bytes;         /* device memory of the scene this context renders (shared by a context and its views) */
+    uint64_t slot_bytes;          /* device memory of this frame slot: eye records, overflow pool, feedback, wavefront queues */
+    uint64_t overflow_pool_bytes; /* of which: the tile kernel's pool of window-overflow bags */
+    uint32_t overflow_chunks;     /* chunks (96 KiB) in that pool */
+    uint32_t overflow_demand;     /* most chunks a finished frame of the current launch geometry asked for */
+} grt_memory_info;
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
        GRT_OPT_KERNEL = 2   /* 0 = auto: camera-ray frames on the tile kernel (grt_render_tile.hip: BVH culling per child box
@@ -143,7 +155,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_COST_RADIUS = 13       /* scheduling feedback under a moving camera: a tile's cost is the largest of last frame's costs
                                          within value tiles of it (default 4; 0 = the tile's own cost) */,
        GRT_OPT_SIZE_CLASSES = 14      /* 1 (default): proxies much larger than average get subtrees of their own in the Gaussian LBVH
-                                         (size class in the top Morton bits); 0: plain Morton order.  Process-wide; next build */,
+                                         (size class in the top Morton bits); 0: plain Morton order.  Per context; next build */,
        GRT_OPT_COLD_ESTIMATE = 15     /* 1 (default): a frame with no previous-frame costs (first frame, new size) launches its tiles in the
                                          order of the number of particle centres projecting into them; 0: screen order */,
        GRT_OPT_BUNDLE_ROUNDS = 16     /* mesh frames on the tile kernel: how many bounce iterations trace their Gaussian segment wave-
@@ -154,12 +166,23 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          1024, doubled for GRT_GLASS.  Same image for every value */,
        GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 256 = 25 %) */,
        GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
+       /* testing knobs (frames never change; speed and the failure signal do) */
+       GRT_OPT_OVF_CHUNKS = 21        /* tile kernel's pool of window-overflow bags: 0 (default) = sized from the demand of the
+                                         frames before; n > 0: exactly n chunks; < 0: no pool (every overflow costs another pass) */,
+       GRT_OPT_OVF_ENTRIES = 22       /* per-lane capacity of a bag actually used, 1..96 (0 = default 96) */,
+       GRT_OPT_MAX_ITERS = 23         /* step watchdog of the tile kernel (0 = default 2^21): a tile over it gives up on its rays
+                                         and sets the sticky error word */,
        GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
                                          segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
                                          finishes it (default 128).  Same image for every value */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
+/* A view: a frame slot of its own (stream, eye records, scheduling feedback, overflow pool, queues, counters, error
+ * word) that renders `scene`'s Gaussians, BVHs and meshes.  Scene calls (grt_upload_gaussians, grt_build_bvh,
+ * grt_set_meshes, grt_update_meshes, GRT_OPT_LEAF_MAX / GRT_OPT_SIZE_CLASSES) are refused on a view.  Destroying a
+ * scene with live views is deferred until the last view is destroyed. */
+GRT_API int grt_create_view(grt_ctx* scene, grt_ctx** out);
 GRT_API void grt_destroy(grt_ctx* ctx);
 GRT_API const char* grt_last_error(const grt_ctx* ctx); /* ctx may be NULL: last error of grt_create */
 GRT_API int grt_set_option(grt_ctx* ctx, int option, int value);
@@ -173,6 +196,7 @@ GRT_API int grt_set_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_mesh
  * IAS on every gizmo frame and leaks the old ones, src/GaussianTracer.cpp:711-794).  GRT_ERR_INVALID when counts differ. */
 GRT_API int grt_update_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_meshes);
 GRT_API int grt_get_bvh_info(const grt_ctx* ctx, grt_bvh_info* out);
+GRT_API int grt_get_memory_info(const grt_ctx* ctx, grt_memory_info* out);
 
 /* ---- render (all asynchronous on `stream`, a hipStream_t; NULL = the context's own stream) ----
  * d_rgb8 : device uchar3 frame, row-major y*width+x (shaders/tracer.cuh:484-496), may be NULL
@@ -194,8 +218,11 @@ GRT_API int grt_assemble_tiles(grt_ctx* ctx, const uint8_t* d_gathered, uint32_t
 /* d_rays[n][6] = origin, direction (device); d_rgbf[n][3] */
 GRT_API int grt_render_rays(grt_ctx* ctx, const grt_params* p, const float* d_rays, uint64_t n, float* d_rgbf,
                             void* stream);
+/* Waits for the context's stream and the last frame launched through this context (whatever stream it went to), then
+ * reads the sticky device error word: GRT_ERR_LIMIT (text in grt_last_error, word cleared) when a wave had to give up on
+ * live rays since the last check — the reference throws on traversal trouble (src/Exception.h:31-80). */
 GRT_API int grt_sync(grt_ctx* ctx);
-GRT_API int grt_get_counters(grt_ctx* ctx, grt_counters* out); /* syncs; counters of the last render */
+GRT_API int grt_get_counters(grt_ctx* ctx, grt_counters* out); /* syncs; counters of the last render; error word as grt_sync */
 /* device time (ms, HIP events on the launch stream) of the last render's kernel; syncs */
 GRT_API int grt_last_kernel_ms(grt_ctx* ctx, float* ms);
 

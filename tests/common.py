@@ -40,3 +40,14 @@ def make_scene(seed, n, width, height, **kw):
     p = grt.default_params(width, height, center, **kw)
     sc = O.Scene(acts_to_particles(acts))
     return acts, p, sc, to_oracle_params(p), center
+
+
+def u8_matches(got_u8, ref_u8, ref_f32, tol=1e-4):
+    """Per value: the 8-bit frame EQUALS the oracle's, except where the oracle's radiance lies within `tol` of a
+    quantisation step (x * 256 within tol * 256 of an integer), where a radiance difference below the tolerance may
+    legitimately move the level by one.  Returns the boolean array (use .all(), or a fraction where geometry differs
+    by ulps)."""
+    du = np.abs(np.asarray(got_u8).astype(np.int32) - np.asarray(ref_u8).astype(np.int32))
+    x = np.clip(np.asarray(ref_f32, dtype=np.float64), 0.0, 1.0) * 256.0
+    near_step = np.abs(x - np.round(x)) <= tol * 256.0
+    return (du == 0) | ((du == 1) & near_step)

@@ -7,7 +7,7 @@ import pytest
 
 import grt
 import oracle as O
-from common import acts_to_particles, to_oracle_params
+from common import acts_to_particles, to_oracle_params, u8_matches
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "gaussian-ray-tracing_amd", "grt_render")
@@ -71,9 +71,16 @@ def test_cli_frame_matches_oracle(tmp_path):
     assert "Mrays/s" in r.stdout
     p = grt.default_params(160, 96, grt.gaussian_center(acts["pos"]))
     sc = O.Scene(acts_to_particles(acts))
-    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    ref, ref_f32, cnt = sc.render(to_oracle_params(p))
     got = _read_ppm(out)
-    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and cnt["hit_evals"] > 160 * 96
+    # the exact-u8 rule of the parity tests: equal, except within 1e-4 of a quantisation step
+    assert u8_matches(got, ref, ref_f32).all() and cnt["hit_evals"] > 160 * 96
+    # the frame as .npy (the renderer's own row order): numpy.load gives the same bytes
+    npy = str(tmp_path / "f.npy")
+    r = subprocess.run([CLI, "-p", ply, "--width", "160", "--height", "96", "--out", npy], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    arr = np.load(npy)
+    assert arr.shape == (96, 160, 3) and arr.dtype == np.uint8 and (arr == got).all()
     # the same frame as PNG (stored-deflate writer in the CLI): decodes to the same bytes
     png = str(tmp_path / "f.png")
     r = subprocess.run([CLI, "-p", ply, "--width", "160", "--height", "96", "--out", png], capture_output=True, text=True)
@@ -114,9 +121,9 @@ def test_cli_mirror_mesh_matches_oracle(tmp_path, kind):
     p = grt.default_params(128, 96, center, mesh_type=grt.MIRROR, max_bounces=3)
     sc = O.Scene(acts_to_particles(acts))
     sc.set_mesh(v, n, f)
-    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    ref, ref_f32, cnt = sc.render(to_oracle_params(p))
     got = _read_ppm(out)
-    bad = (np.abs(got.astype(int) - ref.astype(int)) > 1).any(-1).mean()
+    bad = (~u8_matches(got, ref, ref_f32)).any(-1).mean()  # (the numpy sphere's vertices differ from sinf's by ulps)
     assert bad <= tol_frac, bad
     assert cnt["segments"] > cnt["rays"]
 
@@ -145,9 +152,9 @@ def test_cli_viewer_glue_row_zero_is_the_bottom_and_drag_refits(tmp_path):
     p = grt.default_params(W, H, center, mesh_type=grt.MIRROR, max_bounces=3)
     sc = O.Scene(acts_to_particles(acts))
     sc.set_mesh(vv, n, fcs)
-    ref, _, cnt = sc.render(to_oracle_params(p), want_f32=False)
+    ref, ref_f32, cnt = sc.render(to_oracle_params(p))
     assert cnt["segments"] > cnt["rays"]
-    bad = (np.abs(buf.astype(int) - ref.astype(int)) > 1).any(-1).mean()
+    bad = (~u8_matches(buf, ref, ref_f32)).any(-1).mean()
     assert bad <= 2e-3, bad  # float association of (v + pos) + move may differ by an ulp from the facade's matrix product
     top, bottom = buf[H - 8:].astype(int).sum(), buf[:8].astype(int).sum()
     assert top != bottom  # the frame is not symmetric: the orientation check above has teeth

@@ -9,7 +9,7 @@ import pytest
 
 import grt
 import oracle as O
-from common import acts_to_particles, make_scene, to_oracle_params
+from common import acts_to_particles, make_scene, to_oracle_params, u8_matches
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -42,11 +42,9 @@ def compare(gpu_f32, ref_f32, gpu_u8=None, ref_u8=None, tol=TOL, max_outlier_fra
     if bad.any():
         assert d[bad].max() <= max_outlier, f"outlier of {d[bad].max():.3e} (bound {max_outlier})"
     if gpu_u8 is not None:
-        du = np.abs(gpu_u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
-        x = np.clip(ref_f32.astype(np.float64), 0.0, 1.0) * 256.0
-        near_step = np.abs(x - np.round(x)) <= tol * 256.0
-        ok = (du == 0) | ((du == 1) & near_step) | bad[..., None]
-        assert ok.all(), f"{(~ok).sum()} 8-bit values differ away from a quantisation step (max {du.max()})"
+        g8 = gpu_u8.cpu().numpy() if hasattr(gpu_u8, "cpu") else gpu_u8
+        ok = u8_matches(g8, ref_u8, ref_f32, tol) | bad[..., None]
+        assert ok.all(), f"{(~ok).sum()} 8-bit values differ away from a quantisation step"
     return d.max()
 
 

@@ -1,0 +1,209 @@
+"""Frame slots, scratch memory and the failure signal of the HIP library (round 3):
+views (several frame slots on one scene), the demand-sized pool of window-overflow bags and its exhausted / pruned /
+truncated paths, the sticky device error word, grt_update_meshes' topology checks."""
+import numpy as np
+import pytest
+
+import grt
+import oracle as O
+from common import acts_to_particles, make_scene, to_oracle_params
+from test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_cluster_camera(n=40000, W=128, H=96, seed=61):
+    """The eye in the densest cell of the scene: hundreds of proxies contain it, every window overflows at once."""
+    acts, p0, sc, op0, center = make_scene(seed, n, W, H, scale_boost=1.3)
+    h, edges = np.histogramdd(acts["pos"], bins=24, range=[(-1.5, 1.5)] * 3)
+    i = np.unravel_index(np.argmax(h), h.shape)
+    eye = tuple(float((edges[k][i[k]] + edges[k][i[k] + 1]) / 2) for k in range(3))
+    return acts, grt.default_params(W, H, center, eye=eye), sc
+
+
+def test_views_share_one_scene_and_render_the_same_frames():
+    """grt_create_view: a second frame slot (own eye records, feedback, overflow pool, error word) on the parent's
+    scene.  Same bytes as the parent for different cameras, interleaved on two streams; scene calls are refused on a
+    view; a scene change through the parent reaches the view; the parent may be destroyed first."""
+    import torch
+    acts, p, sc, op, center = make_scene(23, 20000, 192, 128, scale_boost=0.4)
+    q = grt.default_params(192, 128, center, eye=(1.2, 0.5, 2.4))
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    v = tr.view()
+    ref_p = tr.render(p, want_f32=True); ref_p = (ref_p[0].clone(), ref_p[1].clone())
+    ref_q = tr.render(q, want_f32=True); ref_q = (ref_q[0].clone(), ref_q[1].clone())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):  # the two slots in flight together, each with its own camera (own eye records)
+        with torch.cuda.stream(s1):
+            a = tr.render(p, want_f32=True)
+        with torch.cuda.stream(s2):
+            b = v.render(q, want_f32=True)
+        torch.cuda.synchronize()
+        assert (a[0] == ref_p[0]).all() and (a[1] == ref_p[1]).all()
+        assert (b[0] == ref_q[0]).all() and (b[1] == ref_q[1]).all()
+    tr.check(); v.check()
+    mp, mv = tr.memory_info(), v.memory_info()
+    assert mp["scene_bytes"] == mv["scene_bytes"] > 20000 * 64
+    assert mv["slot_bytes"] > 0 and mv["overflow_pool_bytes"] <= mv["slot_bytes"]  # eye records + scratch, no scene replica
+    assert v.bvh_info()["n_proxies"] == tr.bvh_info()["n_proxies"]
+    with pytest.raises(grt.GrtError):
+        v.upload(acts)
+    with pytest.raises(grt.GrtError):
+        v.set_meshes([grt.plane_mesh((0, 0, 1))])
+    with pytest.raises(grt.GrtError):
+        v.set_option(grt.OPT_LEAF_MAX, 2)
+    with pytest.raises(grt.GrtError):
+        grt.Tracer(scene=v)  # a view of a view
+    # a new scene through the parent: the view renders it (its cached eye records / launch order are dropped)
+    acts2, p2, sc2, op2, _ = make_scene(24, 9000, 192, 128, scale_boost=0.4)
+    tr.upload(acts2)
+    a = tr.render(p2, want_f32=True)
+    b = v.render(p2, want_f32=True)
+    torch.cuda.synchronize()
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    ref_u8, ref_f32, _ = sc2.render(op2)
+    compare(b[1], ref_f32, b[0], ref_u8)
+    # the parent is destroyed first: the scene lives on until its last view goes
+    tr.close()
+    b2 = v.render(p2, want_f32=True)
+    torch.cuda.synchronize()
+    assert (b2[0] == b[0]).all()
+    v.close()
+
+
+def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
+    """The pool of window-overflow bags: sized from the demand of the frames before; with too few chunks (or none) the
+    tiles that find it empty drop events for good and go again (grt_render_tile.hip: `chunk = kNoRoot - 1`) — more
+    passes, the same bytes."""
+    acts, p, sc = _dense_cluster_camera()
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    ref8, reff = tr.render(p, want_f32=True)
+    ref8, reff = ref8.clone(), reff.clone()
+    c0 = tr.counters()
+    n_tiles = (128 // 8) * (96 // 8)
+    tr.render(p); tr.sync(); tr.render(p); tr.sync()
+    m = tr.memory_info()
+    assert 0 < m["overflow_demand"] <= n_tiles              # the demand was read back behind the frames ...
+    assert m["overflow_demand"] <= m["overflow_chunks"] <= n_tiles  # ... and the pool covers it, never more than a chunk per tile
+    a8, af = tr.render(p, want_f32=True)
+    c1 = tr.counters()                                      # steady state: no tile finds the pool empty
+    assert (a8 == ref8).all() and (af == reff).all() and c1["rounds"] <= c0["rounds"]
+    rounds = {}
+    for chunks in (2, -1):
+        tr.set_option(grt.OPT_OVF_CHUNKS, chunks)
+        for _ in range(2):
+            a8, af = tr.render(p, want_f32=True)
+            c = tr.counters()
+            assert (a8 == ref8).all() and (af == reff).all(), chunks
+            assert c["stall_exits"] == 0 and c["hit_evals"] == c0["hit_evals"]
+        rounds[chunks] = c["rounds"]
+        assert tr.memory_info()["overflow_chunks"] == max(chunks, 0)
+    assert rounds[-1] > rounds[2] > c1["rounds"]            # fewer bags, more passes
+    tr.set_option(grt.OPT_OVF_CHUNKS, 0)
+    tr.render(p); tr.sync()
+    a8, af = tr.render(p, want_f32=True)
+    assert (a8 == ref8).all() and tr.counters()["rounds"] == c1["rounds"]
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p), threads=8)
+    compare(reff, ref_f32, ref8, ref_u8)
+    assert rc["hit_evals"] == c0["hit_evals"]
+    tr.close(); sc.close()
+
+
+def test_full_bags_of_equal_keys_are_truncated():
+    """bag_prune's last resort: a full bag whose entries all lie at the SAME distance cannot be cut at a distance
+    threshold (the sample's median keeps everything), so its last quarter goes (`trunc`).  200 identical Gaussians
+    around the eye: every ray leaves all of them at exactly the same t.  With 40-entry bags the branch runs over and
+    over; the frame is the streaming kernel's and the per-lane kernel's bit for bit, and the oracle's."""
+    raw = grt.synth_scene(71, 3000)
+    eye = np.float32([0.3, -0.2, 0.4])
+    raw["pos"][:200] = eye
+    raw["scale"][:200] = np.log(np.float32(0.35))
+    raw["rot"][:200] = np.float32([0.8, 0.1, -0.5, 0.3])
+    raw["opacity"][:200] = np.float32(-3.5)  # sigmoid -> 0.029: hittable (> alpha_min), and the rays stay alive through all of them
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    p = grt.default_params(64, 48, center + np.float32([0.5, 0.2, -1.0]), eye=tuple(float(x) for x in eye))
+    frames, cnts = {}, {}
+    for kernel, entries in ((0, 0), (0, 40), (0, 8), (3, 0), (1, 0)):
+        t = grt.Tracer(0)
+        t.set_option(grt.OPT_KERNEL, kernel)
+        t.set_option(grt.OPT_OVF_ENTRIES, entries)
+        t.upload(acts)
+        t.set_option(grt.OPT_COUNTERS, 1)
+        u8, f32 = t.render(p, want_f32=True)
+        frames[(kernel, entries)] = (u8.clone(), f32.clone())
+        cnts[(kernel, entries)] = t.counters()
+        t.close()
+    u8, f32 = frames[(0, 0)]
+    for k, fr in frames.items():
+        assert bool((fr[0] == u8).all()) and bool((fr[1] == f32).all()), k
+        assert cnts[k]["stall_exits"] == 0 and cnts[k]["hit_evals"] == cnts[(0, 0)]["hit_evals"], k
+    assert cnts[(0, 0)]["hit_evals"] > 100 * cnts[(0, 0)]["rays"]  # the rays leave the identical proxies one after another until they saturate
+    assert cnts[(0, 8)]["rounds"] > cnts[(0, 40)]["rounds"] > cnts[(0, 0)]["rounds"]  # smaller bags: truncated more often
+    sc = O.Scene(acts_to_particles(acts))
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p), threads=8)
+    compare(f32, ref_f32, u8, ref_u8)
+    assert rc["hit_evals"] == cnts[(0, 0)]["hit_evals"]
+    sc.close()
+
+
+def test_watchdog_sets_the_sticky_error_word_in_the_production_kernel():
+    """A wave that gives up on live rays must be REPORTED with the counters off: the tile kernel's step watchdog
+    (forced here with a tiny GRT_OPT_MAX_ITERS) ORs its reason into the context's device error word and grt_sync
+    returns GRT_ERR_LIMIT with text, once; the next frame (watchdog back to normal) is clean and correct."""
+    acts, p, sc, op, _ = make_scene(25, 20000, 128, 96, scale_boost=0.4)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    ref8, _ = tr.render(p)
+    ref8 = ref8.clone()
+    tr.check()
+    tr.set_option(grt.OPT_MAX_ITERS, 3)
+    bad8, _ = tr.render(p)
+    with pytest.raises(grt.GrtError) as ei:
+        tr.check()
+    assert ei.value.code == grt.ERR_LIMIT and "watchdog" in str(ei.value)
+    assert not bool((bad8 == ref8).all())  # pixels ARE missing hits: that is what the error says
+    tr.check()  # read once, cleared
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    tr.render(p)
+    with pytest.raises(grt.GrtError):
+        tr.counters()  # the instrumented kernel reports it too (and counts it in stall_exits)
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    tr.set_option(grt.OPT_MAX_ITERS, 0)
+    ok8, _ = tr.render(p)
+    tr.check()
+    assert bool((ok8 == ref8).all())
+    tr.close(); sc.close()
+
+
+def test_update_meshes_checks_the_topology_per_mesh():
+    """grt_update_meshes re-fits the tree built by grt_set_meshes: it must refuse anything but the same meshes moved —
+    per-mesh counts (two meshes that swap sizes keep the totals) and the face indices themselves."""
+    acts, p, sc, op, center = make_scene(26, 4000, 96, 64, scale_boost=0.4, mesh_type=grt.MIRROR, max_bounces=3)
+    a = grt.sphere_mesh(center + np.float32([0, 0, 1.0]), tess_u=16, tess_v=8)
+    b = grt.plane_mesh(center + np.float32([0.4, 0, 1.2]))
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_meshes([a, b])
+    ref8, _ = tr.render(p); ref8 = ref8.clone()
+    tr.update_meshes([a, b])  # same meshes: fine, same frame
+    same8, _ = tr.render(p)
+    assert bool((same8 == ref8).all())
+    with pytest.raises(grt.GrtError):
+        tr.update_meshes([b, a])  # same totals, other per-mesh counts
+    with pytest.raises(grt.GrtError):
+        tr.update_meshes([a])
+    flipped = (a[0], a[1], a[2][:, ::-1].copy())
+    with pytest.raises(grt.GrtError):
+        tr.update_meshes([flipped, b])  # same counts, other indices
+    moved = ((a[0] + np.float32([0.1, 0.05, 0])).astype(np.float32), a[1], a[2])
+    tr.update_meshes([moved, b])
+    m8, mf = tr.render(p, want_f32=True)
+    sc.set_mesh(np.concatenate([moved[0], b[0]]), np.concatenate([moved[1], b[1]]),
+                np.concatenate([moved[2], b[2] + len(moved[0])]))
+    ref_u8, ref_f32, _ = sc.render(op)
+    compare(mf, ref_f32, m8, ref_u8)
+    tr.close(); sc.close()
