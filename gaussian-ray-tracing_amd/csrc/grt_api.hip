@@ -246,6 +246,21 @@ static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
     return h;
 }
 
+// The tile kernel's give-up reasons travel in the per-tile cost words (see the watchdog in grt_render_tile.hip): a cost
+// above the step watchdog = the watchdog fired, high bits = stack guard / two passes without progress.  One pass over
+// the costs right behind the frame ORs them into the context's sticky error word.
+__global__ void k_check_costs(const uint32_t* __restrict__ cost, uint32_t n, uint32_t max_iters, uint32_t* __restrict__ err_word)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cost[i];
+    uint32_t e = 0;
+    if (c & kCostStackBit) e |= kErrStack;
+    if (c & kCostStallBit) e |= kErrStall;
+    if ((c & ~(kCostStackBit | kCostStallBit)) > max_iters) e |= kErrWatchdog;
+    if (e) atomicOr(err_word, e);
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -770,14 +785,14 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
                                (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
 }
 
-static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units)
+static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units, bool need_cost)
 {
     a.order = nullptr;
     a.cost = nullptr;
     a.n_heavy = nullptr;
     a.heavy_role = 0;
     a.n_units = n_units;
-    if (!c->opt_feedback || n_units == 0) return GRT_OK;
+    if ((!c->opt_feedback && !need_cost) || n_units == 0) return GRT_OK;
     const uint64_t sig[6] = {a.mode | ((uint64_t)n_units << 8), a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
                              ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
@@ -790,6 +805,14 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
+    }
+    if (!c->opt_feedback) { // no scheduling feedback: the cost words are only collected for k_check_costs (tile kernel)
+        CHK(c, hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * n_units, s));
+        a.cost = c->d_cost;
+        c->cost_valid = false;
+        c->order_ready = false;
+        c->cost_zeroed = false;
+        return GRT_OK;
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     const grt_ctx* sc = scene_of(c);
@@ -902,7 +925,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         // kernels per 16x16 block (same test as launch_render)
         const uint32_t h = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
         const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
-        int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks);
+        int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks,
+                                   uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max));
         if (rcf != GRT_OK) return rcf;
     }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
@@ -1004,6 +1028,11 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     // ---- behind the frame, outside its timing (grt_last_kernel_ms brackets ev0..ev1; the feedback kernels below are
     //      ~60 us per frame under a moving camera and are what `frame ms - kernel ms` of bench.py's orbit leg shows) ----
     bool tail = false;
+    if (rc == GRT_OK && tile_kernel && a.cost) { // the tiles' give-up reasons -> sticky error word (a frame that repeats the
+        // last one exactly collects no costs and is not checked again: it is the same computation)
+        hipLaunchKernelGGL(k_check_costs, dim3((a.n_units + 255u) / 256u), dim3(256), 0, s, c->d_cost, a.n_units, a.max_iters, c->d_err);
+        tail = true;
+    }
     if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order
         if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
             c->order_ready = true;

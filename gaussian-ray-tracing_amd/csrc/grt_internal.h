@@ -153,6 +153,7 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
 constexpr int kNumCounters = 8;
 // bits of RenderArgs::err_word
 constexpr uint32_t kErrWatchdog = 1u, kErrStack = 2u, kErrStall = 4u;
+constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // give-up reasons in a tile's cost word
 constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
 constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
 // The stack receives the batch that overflowed (<= 64) plus up to kTileWide - 1 siblings per 8-wide level below it

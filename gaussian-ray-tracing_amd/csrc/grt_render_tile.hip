@@ -769,9 +769,17 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                     }
                 }
                 if (done) break;
-                if (++iters > a.max_iters) { // watchdog: never reached by design; a reported failure beats a hung GPU
+                // watchdog: never reached by design; a reported failure beats a hung GPU.  HOW it is reported matters: any
+                // store to an error word from this kernel (in the loop, behind it, atomic or plain) re-shuffled the register
+                // allocation of the hot loop and cost MODE 0 12-16 % (2.18 -> 2.44-2.53 ms on C3, six formulations measured).
+                // So a camera-ray tile's reasons travel in the cost word it writes anyway (iters > max_iters = watchdog, high
+                // bits = stack guard / stalled passes) and k_check_costs (grt_api.hip) turns them into the sticky error
+                // word right behind the frame.  A bundle (MODE 1) in trouble gives up as if over budget and its rays go one
+                // per wave; that last resort (MODE 2: 2 waves per SIMD, registers to spare) reports directly.
+                if (++iters > a.max_iters) {
+                    if (MODE == 1) { aborted = true; break; } // a bundle gives up as if over budget: its rays go one per wave
                     c.stall_exits += alive ? 1u : 0u;
-                    if (lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrWatchdog);
+                    if (SINGLE && lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrWatchdog);
                     watchdog = true;
                     break;
                 }
@@ -1038,8 +1046,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                     } else {
                         if (nc > nf && dsp + (nc - nf) > kStack) { // cannot happen for the tree heights the launcher admits
                             c.stall_exits += alive ? 1u : 0u;
-                            if (lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrStack);
+                            if (MODE == 1) { aborted = true; break; }
                             watchdog = true;
+                            iters |= kCostStackBit;
+                            if (SINGLE && lane == 0u && wave_any(alive)) atomicOr(a.err_word, kErrStack);
                             break;
                         }
                         if (want) {
@@ -1063,7 +1073,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
             stalls = parked ? stalls : (progressed ? 0u : stalls + 1u);
             const bool again = alive && (lost != kKeyInvalid);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
-            if (wave_any(again && stalls >= 2u) && lane == 0u) atomicOr(a.err_word, kErrStall); // (never seen: rare by construction)
+            if (wave_any(again && stalls >= 2u)) { // (never seen)
+                if (MODE == 1) { aborted = true; break; }
+                iters |= kCostStallBit;
+                if (SINGLE && lane == 0u) atomicOr(a.err_word, kErrStall);
+            }
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
         if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[unit], iters);

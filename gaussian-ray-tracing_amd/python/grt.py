@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libgrt_hip.so")
+# (GRT_LIB: a diagnostic build of the same library, e.g. make EXTRA=-DGRT_TILE_DIAG — profiling only)
+LIB_PATH = os.environ.get("GRT_LIB") or os.path.join(_PKG, "libgrt_hip.so")
 
 
 class GrtError(RuntimeError):
