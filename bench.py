@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 TRAFFIC_FILE = os.path.join("profiles", "traffic.json")
 
 
-def kernel_name(variant, with_mesh, sh_degree, leaf_max=4):
+def kernel_name(variant, with_mesh, sh_degree, leaf_max=4, pieces=False):
     """Which kernel grt_render dispatches the Gaussian segment of camera rays to (csrc/grt_render.hip: launch_render)."""
     sh = "true" if sh_degree > 0 else "false"
     mesh = "true" if with_mesh else "false"
@@ -63,7 +63,7 @@ def kernel_name(variant, with_mesh, sh_degree, leaf_max=4):
     if variant == 2 and not with_mesh:
         return f"grt::k_render_wave<false, {sh}>"
     if variant in (0, 5) and leaf_max <= 4:
-        return f"grt::k_render_tile<false, {sh}, {mesh}, 0>"
+        return f"grt::k_render_tile<false, {sh}, {mesh}, 0, {'true' if pieces else 'false'}>"
     return f"grt::k_render_stream<false, {sh}, {mesh}>"
 
 
@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (cold frame, orbit, the other pipelining depth)")
     ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
+    ap.add_argument("--split", type=int, default=-1, help="GRT_OPT_SPLIT (piece length of the spatial splits, quarters of the typical proxy diagonal; 0 = off; -1 = library default)")
     ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one process, one GPU: do the work of ONE rank of an N-rank run (tile list, frame slots, "
@@ -224,6 +225,8 @@ def main():
     for k in range(n_ctx):  # ONE scene; every further frame slot is a view of it (own stream state, eye records, scratch)
         if k == 0:
             t = grt.Tracer(local_rank)
+            if args.split >= 0:
+                t.set_option(grt.OPT_SPLIT, args.split)
             t.upload(acts)
             if mesh is not None:
                 t.set_meshes([mesh])
@@ -253,7 +256,11 @@ def main():
         else:
             t.render_tiles(q, TILE, TILE, t_rank, t_world, my_cnt, out_u8=loop.mines[0])
 
-    # ---- instrumented frame (outside the timed region): counters for rays and algorithmic bytes ----
+    # ---- instrumented frame (outside the timed region): counters for rays and algorithmic bytes; a steady-state frame
+    #      (the first frames of a context size its scratch: their pass counts are not the timed frames') ----
+    for _ in range(3):
+        one_frame()
+        tr.sync()
     tr.set_option(grt.OPT_COUNTERS, 1)
     one_frame()
     cnt = tr.counters()
@@ -413,7 +420,7 @@ def main():
                        "proxy_tests_per_ray": round(tot["proxy_tests"] / max(tot["segments"], 1), 1),
                        "fetched_record_bytes_per_ray": round(16 * tot["rec_fetches"] / max(tot["segments"], 1), 1),
                        "stall_exits": tot["stall_exits"],
-                       "bvh_height": info["height"], "n_proxies": info["n_proxies"], "bvh_build_ms": round(info["build_ms"], 2),
+                       "bvh_height": info["height"], "n_proxies": info["n_proxies"], "n_bvh_primitives": info["n_primitives"], "bvh_build_ms": round(info["build_ms"], 2),
                        "setup_s": round(setup_s, 2), "kernel_variant": args.kernel,
                        "scheduling": "8x8 tiles launched heaviest-first from the previous frame's per-tile cost "
                                      "(steady state of an interactive viewer); kernel_ms_cold / frame_ms_cold (wall, synchronised): a frame with no "
@@ -427,7 +434,7 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name(args.kernel, with_mesh, args.sh_degree), "algorithmic_bytes_per_launch": int(b_alg),
+                         "kernel": kernel_name(args.kernel, with_mesh, args.sh_degree, pieces=info["n_primitives"] > info["n_proxies"]), "algorithmic_bytes_per_launch": int(b_alg),
                          "floor_bytes_per_launch": int(b_min),
                          "floor_frac": round(b_min / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "valu_issue": valu},

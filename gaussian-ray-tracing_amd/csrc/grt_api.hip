@@ -1,8 +1,13 @@
 // grt_api.hip — C ABI of libgrt_hip.so (include/grt.h): context, scene upload, BVH build driver,
 // render entry points.  No CPU fallback: every entry point that needs the GPU fails loudly without one.
-#include <hip/hip_runtime.h>
-
+#include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
 #include <cstring>
 #include <string>
 #include <vector>
@@ -80,17 +85,159 @@ __global__ void k_proxy_boxes(const float* __restrict__ pos, const float* __rest
     hi[i] = make_float4(h[0], h[1], h[2], 0.0f);
 }
 
+// ---- spatial splits of large anisotropic proxies -------------------------------------------------------------------
+// The LBVH bounds every proxy by its world AABB.  A needle or a sheet that is not axis-aligned fills a vanishing part of
+// that box: a tile's thin frustum crosses thousands of such boxes without ever touching the proxies inside, and the
+// traversal runs with a frontier that never clears (the C3a scene: 608 child boxes culled and 774 proxies slab-tested
+// per ray for 67 composited events).  OptiX meets the same scene with an ORIENTED proxy per particle (an instance
+// transform over 20 triangles, src/GaussianTracer.cpp:297-317,401-420).  Here a large proxy whose box is mostly empty
+// enters the tree as several PIECES: the proxy-local box [-tt s, tt s]^3 (tt = 1.0705: the icosahedron's extent along
+// its principal axes) is cut into p1 x p2 x p3 cells, each bounded by the world AABB of its cell, clipped to the
+// proxy's own AABB.  Every piece refers to the WHOLE particle (the record is the particle's; the exact test is
+// unchanged), the cells cover the proxy, so the piece that contains a ray's entry (exit) point is reached no later than
+// that event: the hits are the same.  A ray that crosses several pieces of one particle meets it several times with
+// bit-identical keys (t, id, entry/exit).  An EVENT BELONGS TO THE PIECE WHOSE CELL HOLDS ITS POINT (piece_owns,
+// grt_device.h: the cell index of o_g + t d_g, from the descriptor in the record's last word), so each event is
+// reported once; where the wave-per-tile kernels carry the exit with the entry a repeat is still possible (the entry
+// is composited, then the exit's own piece turns up) and they drop it: an event at or before the last composited key is
+// not inserted, and of equal keys that meet in a window only the first is composited.  Pure acceleration-structure
+// work, as splitting is inside OptiX: pixels, hit counters and the oracle (which builds its own BVH) are untouched.
+constexpr float kIcoTT = 1.0704663f; // (1 + sqrt 5) / (2 rr), rr = (3 + sqrt 5) / (2 sqrt 3): src/geometry/Icosahedron.h:15-17
+constexpr uint32_t kMaxPieces = 512u;
+
+struct PieceGrid { uint32_t p[3]; };
+
+// how particle i is cut: pieces per principal axis (1,1,1 = not split).  tau = the piece length aimed at.
+__device__ __forceinline__ PieceGrid piece_grid(const float* __restrict__ scale, const float* __restrict__ quat, float s, uint32_t i,
+                                                float tau, float4 lo, float4 hi)
+{
+    PieceGrid g{{1u, 1u, 1u}};
+    if (!(s > 0.0f) || !(tau > 0.0f)) return g;
+    const float e[3] = {scale[i * 3] * s * kIcoTT, scale[i * 3 + 1] * s * kIcoTT, scale[i * 3 + 2] * s * kIcoTT};
+    const float emin = fminf(e[0], fminf(e[1], e[2])), emax = fmaxf(e[0], fmaxf(e[1], e[2]));
+    if (!(2.0f * emax > tau)) return g;
+    float Rg[9];
+    mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
+    float len = fmaxf(tau, 2.0f * emin); // cells about as long as the proxy is thick: their boxes come out compact
+    uint32_t p[3];
+    for (int it = 0; it < 16; it++) {
+        for (int r = 0; r < 3; r++) p[r] = (uint32_t)fminf(fmaxf(ceilf(2.0f * e[r] / len), 1.0f), 32.0f); // (5 bits per axis: piece_desc)
+        if (p[0] * p[1] * p[2] <= kMaxPieces) break;
+        len *= 1.5f;
+    }
+    if (p[0] * p[1] * p[2] > kMaxPieces || p[0] * p[1] * p[2] <= 1u) return g;
+    // worth it only when the cells' boxes hold much less than the proxy's box does (an axis-aligned needle gains nothing)
+    float v1 = (float)(p[0] * p[1] * p[2]);
+    for (int k = 0; k < 3; k++) {
+        float h = 0.0f; // half-size of a cell's box along world axis k (column c of R = Rg[c*3 + k])
+        for (int c = 0; c < 3; c++) h += fabsf(Rg[c * 3 + k]) * (e[c] / (float)p[c]);
+        v1 *= fminf(2.0f * h, (k == 0) ? hi.x - lo.x : (k == 1) ? hi.y - lo.y : hi.z - lo.z);
+    }
+    const float v0 = (hi.x - lo.x) * (hi.y - lo.y) * (hi.z - lo.z);
+    if (!(v1 < 0.5f * v0)) return g;
+    g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
+    return g;
+}
+
+__global__ void k_piece_counts(const float* __restrict__ scale, const float* __restrict__ quat, const float* __restrict__ s_arr,
+                               const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, float tau,
+                               uint32_t* __restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, lo[i], hi[i]);
+    counts[i] = g.p[0] * g.p[1] * g.p[2];
+}
+
+// one thread per piece: its owner by binary search in the offsets, its cell, its box
+__global__ void k_piece_boxes(const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ quat,
+                              const float* __restrict__ s_arr, const float4* __restrict__ lo, const float4* __restrict__ hi,
+                              const uint32_t* __restrict__ offs, uint32_t n, uint32_t n_pieces, float tau,
+                              float4* __restrict__ plo, float4* __restrict__ phi, uint32_t* __restrict__ owner,
+                              uint32_t* __restrict__ desc)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pieces) return;
+    desc[j] = 0u;
+    uint32_t a = 0, b = n; // largest i with offs[i] <= j
+    while (b - a > 1u) {
+        const uint32_t m = (a + b) >> 1;
+        if (offs[m] <= j) a = m; else b = m;
+    }
+    const uint32_t i = a;
+    owner[j] = i;
+    const float4 l = lo[i], h = hi[i];
+    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, l, h);
+    if (g.p[0] * g.p[1] * g.p[2] <= 1u) { plo[j] = l; phi[j] = h; return; }
+    uint32_t q = j - offs[i];
+    const uint32_t k0 = q % g.p[0]; q /= g.p[0];
+    const uint32_t k1 = q % g.p[1], k2 = q / g.p[1];
+    const uint32_t kk[3] = {k0, k1, k2};
+    desc[j] = piece_desc(kk, g.p);
+    const float s = s_arr[i];
+    float Rg[9];
+    mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
+    float mid[3], half[3];
+    for (int r = 0; r < 3; r++) {
+        const float e = scale[i * 3 + r] * s * kIcoTT, w = 2.0f * e / (float)g.p[r];
+        mid[r] = -e + ((float)kk[r] + 0.5f) * w;
+        half[r] = 0.5f * w * (1.0f + 1e-5f) + 1e-6f * e; // the cells overlap by a hair: no point of the proxy falls between two
+    }
+    float bl[3], bh[3];
+    const float L[3] = {l.x, l.y, l.z}, H[3] = {h.x, h.y, h.z};
+    for (int k = 0; k < 3; k++) {
+        float c = pos[i * 3 + k], hw = 0.0f;
+        for (int r = 0; r < 3; r++) { c += Rg[r * 3 + k] * mid[r]; hw += fabsf(Rg[r * 3 + k]) * half[r]; }
+        const float m = 2e-5f * (1.0f + fabsf(c) + hw); // rounding of the nine products above, and then some
+        bl[k] = fmaxf(c - hw - m, L[k]);
+        bh[k] = fminf(c + hw + m, H[k]);
+        if (!(bl[k] <= bh[k])) { bl[k] = L[k]; bh[k] = H[k]; } // (cannot happen: the cell meets the proxy's box)
+    }
+    plo[j] = make_float4(bl[0], bl[1], bl[2], 0.0f);
+    phi[j] = make_float4(bh[0], bh[1], bh[2], 0.0f);
+}
+
+// sum over the hittable proxies of log(box diagonal), per workgroup (fixed order; the host adds the partials in double):
+// exp(mean) is the typical proxy size the split length is a multiple of
+__global__ void k_log_diag_partial(const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, float* __restrict__ part,
+                                   uint32_t* __restrict__ cnt)
+{
+    float sum = 0.0f;
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 l = lo[i], h = hi[i];
+        if (l.x <= h.x) {
+            sum += logf(fmaxf(sqrtf((h.x - l.x) * (h.x - l.x) + (h.y - l.y) * (h.y - l.y) + (h.z - l.z) * (h.z - l.z)), 1e-30f));
+            c++;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); c += (uint32_t)__shfl_xor((int)c, off); }
+    __shared__ float ssum[4];
+    __shared__ uint32_t scnt[4];
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = sum; scnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = ssum[0]; uint32_t k = scnt[0];
+        for (uint32_t w = 1; w < (blockDim.x + 63u) / 64u; w++) { t += ssum[w]; k += scnt[w]; }
+        part[blockIdx.x] = t; cnt[blockIdx.x] = k;
+    }
+}
+
 // Proxy record in Morton order, 64 B = 4 x float4:
-//   (mu.x mu.y mu.z s) (A00 A01 A02 opacity) (A10 A11 A12 id-bits) (A20 A21 A22 0)
+//   (mu.x mu.y mu.z s) (A00 A01 A02 opacity) (A10 A11 A12 id-bits) (A20 A21 A22 cell-bits)
 // A = diag(1/scale) * R^T exactly as computeResponse forms it per hit (shaders/tracer.cuh:191-201).
+// (owner / desc: piece -> particle and the piece's cell (piece_desc) when large proxies were split, else nullptr:
+//  primitive = particle; the last word of the record is the cell descriptor, 0 for a whole proxy)
 __global__ void k_gather_records(const float* __restrict__ pos, const float* __restrict__ scale,
                                  const float* __restrict__ quat, const float* __restrict__ opacity,
-                                 const float* __restrict__ s_arr, const uint32_t* __restrict__ order, uint32_t m,
+                                 const float* __restrict__ s_arr, const uint32_t* __restrict__ order,
+                                 const uint32_t* __restrict__ owner, const uint32_t* __restrict__ desc, uint32_t m,
                                  float4* __restrict__ rec)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const uint32_t i = order[j];
+    const uint32_t i = owner ? owner[order[j]] : order[j];
+    const uint32_t cd = desc ? desc[order[j]] : 0u;
     float Rg[9];
     mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
     float A[9];
@@ -103,7 +250,7 @@ __global__ void k_gather_records(const float* __restrict__ pos, const float* __r
     rec[(size_t)j * 4 + 0] = make_float4(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2], s_arr[i]);
     rec[(size_t)j * 4 + 1] = make_float4(A[0], A[1], A[2], opacity[i]);
     rec[(size_t)j * 4 + 2] = make_float4(A[3], A[4], A[5], __uint_as_float(i));
-    rec[(size_t)j * 4 + 3] = make_float4(A[6], A[7], A[8], 0.0f);
+    rec[(size_t)j * 4 + 3] = make_float4(A[6], A[7], A[8], __uint_as_float(cd));
 }
 
 // Eye records: everything in the proxy test that depends on the ray ORIGIN only.  Camera rays share one origin,
@@ -426,6 +573,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
+    else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
     else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; }
     else if (option == GRT_OPT_OVF_ENTRIES) {
         if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
@@ -508,13 +656,74 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         c->err = std::string("grt_build_bvh: hipMalloc: ") + hipGetErrorString(e);
         rc = GRT_ERR_HIP;
     }
+    float4 *d_plo = nullptr, *d_phi = nullptr; // piece boxes (when large proxies are split)
+    uint32_t *d_cnt = nullptr, *d_offs = nullptr, *d_owner = nullptr, *d_desc = nullptr;
+    void* d_scan_tmp = nullptr;
+    uint32_t n_pieces = n;
+    c->n_hittable = 0;
+    for (uint32_t i = 0; i < n; i++) c->n_hittable += (s[i] > 0.0f) ? 1u : 0u;
     if (rc == GRT_OK) {
         (void)hipMemcpyAsync(d_s, s.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream);
         (void)hipEventRecord(c->ev0, c->stream);
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
-        rc = build_lbvh(d_lo, d_hi, n, (uint32_t)c->opt_leaf_max, true, false, c->opt_size_classes, &c->gbvh, c->stream, &c->err);
     }
+    if (rc == GRT_OK && c->opt_split > 0 && n > 1) {
+        // ---- spatial splits (see k_piece_boxes): piece length = opt_split/4 x the geometric-mean proxy diagonal ----
+        float* d_part = nullptr;
+        uint32_t* d_pcnt = nullptr;
+        const int grid = (int)std::min<uint32_t>((n + 255) / 256, 256u);
+        std::vector<float> h_part(grid);
+        std::vector<uint32_t> h_pcnt(grid);
+        size_t tmp_bytes = 0;
+        if ((e = hipMalloc(&d_part, grid * sizeof(float))) != hipSuccess || (e = hipMalloc(&d_pcnt, grid * sizeof(uint32_t))) != hipSuccess ||
+            (e = hipMalloc(&d_cnt, (size_t)n * sizeof(uint32_t))) != hipSuccess || (e = hipMalloc(&d_offs, (size_t)n * sizeof(uint32_t))) != hipSuccess) {
+            c->err = std::string("grt_build_bvh: hipMalloc(split): ") + hipGetErrorString(e);
+            rc = GRT_ERR_HIP;
+        }
+        float tau = 0.0f;
+        if (rc == GRT_OK) {
+            hipLaunchKernelGGL(k_log_diag_partial, dim3(grid), dim3(256), 0, c->stream, d_lo, d_hi, n, d_part, d_pcnt);
+            (void)hipMemcpyAsync(h_part.data(), d_part, grid * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            (void)hipMemcpyAsync(h_pcnt.data(), d_pcnt, grid * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { c->err = std::string("grt_build_bvh: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+        }
+        if (rc == GRT_OK) {
+            double sum = 0.0; uint64_t cnt = 0;
+            for (int b = 0; b < grid; b++) { sum += h_part[b]; cnt += h_pcnt[b]; }
+            if (cnt) tau = (float)(0.25 * c->opt_split * std::exp(sum / (double)cnt));
+        }
+        if (rc == GRT_OK && tau > 0.0f) {
+            hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau, d_cnt);
+            e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, d_offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream);
+            if (e == hipSuccess) e = hipMalloc(&d_scan_tmp, tmp_bytes ? tmp_bytes : 16);
+            if (e == hipSuccess) e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, d_cnt, d_offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream);
+            uint32_t last_off = 0, last_cnt = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&last_off, d_offs + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&last_cnt, d_cnt + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->err = std::string("grt_build_bvh: split scan: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+            const uint64_t total = (uint64_t)last_off + last_cnt;
+            // (a scene where splitting adds less than 2 % of primitives has no population of needles and sheets to speak of:
+            //  it keeps whole proxies — size classes deal with the odd large one — and the kernels without the piece logic)
+            if (rc == GRT_OK && total > (uint64_t)n + n / 50u && total <= (uint64_t)kLeafIndexMask) {
+                n_pieces = (uint32_t)total;
+                if ((e = hipMalloc(&d_plo, (size_t)n_pieces * sizeof(float4))) != hipSuccess || (e = hipMalloc(&d_phi, (size_t)n_pieces * sizeof(float4))) != hipSuccess ||
+                    (e = hipMalloc(&d_owner, (size_t)n_pieces * sizeof(uint32_t))) != hipSuccess ||
+                    (e = hipMalloc(&d_desc, (size_t)n_pieces * sizeof(uint32_t))) != hipSuccess) {
+                    c->err = std::string("grt_build_bvh: hipMalloc(pieces): ") + hipGetErrorString(e);
+                    rc = GRT_ERR_HIP;
+                } else {
+                    hipLaunchKernelGGL(k_piece_boxes, dim3((n_pieces + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat, d_s,
+                                       d_lo, d_hi, d_offs, n, n_pieces, tau, d_plo, d_phi, d_owner, d_desc);
+                }
+            }
+        }
+        (void)hipFree(d_part); (void)hipFree(d_pcnt);
+    }
+    if (rc == GRT_OK)
+        rc = build_lbvh(d_owner ? d_plo : d_lo, d_owner ? d_phi : d_hi, d_owner ? n_pieces : n, (uint32_t)c->opt_leaf_max, true, false,
+                        c->opt_size_classes, &c->gbvh, c->stream, &c->err);
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
         if (c->cap_rec < m) {
@@ -528,7 +737,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         }
         if (rc == GRT_OK)
             hipLaunchKernelGGL(k_gather_records, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale,
-                               c->d_quat, c->d_opacity, d_s, c->gbvh.order, m, c->d_rec);
+                               c->d_quat, c->d_opacity, d_s, c->gbvh.order, d_owner, d_owner ? d_desc : nullptr, m, c->d_rec);
     }
     if (rc == GRT_OK) {
         (void)hipEventRecord(c->ev1, c->stream);
@@ -538,6 +747,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         else (void)hipEventElapsedTime(&c->build_ms, c->ev0, c->ev1);
     }
     (void)hipFree(d_s); (void)hipFree(d_lo); (void)hipFree(d_hi);
+    (void)hipFree(d_plo); (void)hipFree(d_phi); (void)hipFree(d_cnt); (void)hipFree(d_offs); (void)hipFree(d_owner); (void)hipFree(d_desc); (void)hipFree(d_scan_tmp);
     c->have_timing = false;
     c->cost_valid = false;
     c->erec_valid = false;
@@ -691,7 +901,8 @@ int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
     const grt_ctx* sc = scene_of(c);
     memset(o, 0, sizeof(*o));
     o->n_particles = sc->n;
-    o->n_proxies = sc->gbvh.n_prims;
+    o->n_proxies = sc->n_hittable;
+    o->n_primitives = sc->gbvh.n_prims;
     o->n_nodes = sc->gbvh.n_prims ? sc->gbvh.n_prims - 1 : 0;
     o->height = sc->gbvh.height;
     o->mesh_faces = sc->n_faces;
@@ -749,6 +960,7 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     a->pbox = sc->gbvh.pbox;
     a->root_ref = sc->gbvh.root_ref;
     a->n_prox = sc->gbvh.n_prims;
+    a->has_pieces = sc->gbvh.n_prims > sc->n_hittable ? 1u : 0u;
     a->color0 = sc->d_color0;
     a->sh = sc->d_sh;
     a->mnodes = sc->mbvh.nodes;
@@ -869,29 +1081,36 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
 
 // The tile kernel's pool of window-overflow bags: a chunk (kTileOvfChunkBytes = 96 KiB) per tile that overflows.  A tile
 // that finds the pool empty falls back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the
-// default 1 M scene and cost that frame 12 %).  Round 2 held a chunk for EVERY tile of the launch (3.1 GB at 1080p,
-// 12.4 GB at 4K, per frame slot); now the pool follows the DEMAND: the chunk counter of every frame is read back behind
-// it (pinned word, no sync), the pool starts at 3/8 of the tiles (about a third of them overflow on the benchmark scenes)
-// and grows to 1.25 x the largest demand seen + 64 — a frame or two after a camera cut at the latest.  An allocation
-// that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation buffer.
+// default 1 M scene and cost that frame 12 %, and on the needle scene C3a a pool of 3/8 of the tiles made the first
+// frames 2.3 x slower).  Round 2 held a chunk for EVERY tile of the launch for good (3.1 GB at 1080p, 12.4 GB at 4K, per
+// frame slot).  Now the pool follows the DEMAND: the chunk counter of every frame is read back behind it (pinned word, no
+// sync); the first frame of a launch geometry still gets a chunk per tile (or what a sibling frame slot of the same
+// scene has learnt), and as soon as a demand is known the pool is re-sized to 1.25 x the largest demand seen + 64.  An
+// allocation that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation
+// buffer.
 static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
 {
+    grt_ctx* sc = scene_of(c);
     if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
-        c->ovf_demand = std::max(c->ovf_demand, *c->h_ovf_used);
+        c->ovf_demand = std::max(c->ovf_demand, std::max(*c->h_ovf_used, 1u));
         c->ovf_pending = false;
+        if (sc->ovf_hint_units != c->ovf_units || sc->ovf_hint < c->ovf_demand) { sc->ovf_hint_units = c->ovf_units; sc->ovf_hint = c->ovf_demand; }
     }
     if (c->ovf_units != n_tiles) { c->ovf_demand = 0; c->ovf_units = n_tiles; } // another launch geometry: start over
+    const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
+    const uint32_t most = std::min(cap, std::max(n_tiles, 1u));
     uint32_t want;
+    bool known = false;
     if (c->opt_ovf_chunks != 0) {
         want = c->opt_ovf_chunks > 0 ? (uint32_t)c->opt_ovf_chunks : 0u;
-        if (want != c->ovf_chunks) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); c->d_ovf = nullptr; c->ovf_chunks = 0; }
+        known = true;
     } else {
-        const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
-        const uint32_t first = n_tiles - n_tiles / 2u - n_tiles / 8u + 64u; // 3/8 of the tiles
-        const uint32_t seen = c->ovf_demand + c->ovf_demand / 4u + 64u;
-        want = std::min(std::min(cap, std::max(n_tiles, 1u)), std::max(c->ovf_demand ? seen : first, 64u));
+        const uint32_t d = c->ovf_demand ? c->ovf_demand : ((sc->ovf_hint_units == n_tiles) ? sc->ovf_hint : 0u);
+        known = d != 0u;
+        want = known ? std::min(most, d + d / 4u + 64u) : most;
     }
-    if (c->ovf_chunks < want) {
+    const bool shrink = known && (c->opt_ovf_chunks != 0 ? c->ovf_chunks != want : c->ovf_chunks > 2u * want + 256u);
+    if (c->ovf_chunks < want || shrink) {
         if (c->d_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); } // a frame in flight may still use it
         c->d_ovf = nullptr;
         c->ovf_chunks = 0;

@@ -160,6 +160,33 @@ __device__ __forceinline__ bool proxy_sphere_maybe(f3 o_g, f3 d_g, float s)
     return proxy_sphere_maybe_pre(o_g, proxy_sphere_cc(o_g, s), d_g);
 }
 
+// ---- pieces of a split proxy (grt_api.hip: k_piece_boxes) ----
+// The proxy-local box [-tt s, tt s]^3 of Gaussian space (tt = 1.0705: the icosahedron's extent along its principal axes)
+// is cut into p0 x p1 x p2 cells; a piece's descriptor holds its cell (k_r) and the grid (p_r - 1), 5 bits each, bit 31 set.
+constexpr float kIcoTTdev = 1.0704663f;
+__host__ __device__ __forceinline__ uint32_t piece_desc(const uint32_t k[3], const uint32_t p[3])
+{
+    return 0x80000000u | k[0] | ((p[0] - 1u) << 5) | (k[1] << 10) | ((p[1] - 1u) << 15) | (k[2] << 20) | ((p[2] - 1u) << 25);
+}
+// Does the event at distance t of this ray (Gaussian-space origin o_g, direction d_g) belong to the piece?  Its point's
+// cell index along every axis must be the piece's; the outermost cells reach to infinity, so every point has exactly one
+// owner whatever the rounding at the proxy's surface.  (Scheduling only: which piece reports a hit never changes the hit.)
+__device__ __forceinline__ bool piece_owns(uint32_t desc, float s, f3 o_g, f3 d_g, float t)
+{
+    const float inv = 0.5f / (kIcoTTdev * s);
+    const float y[3] = {o_g.x + t * d_g.x, o_g.y + t * d_g.y, o_g.z + t * d_g.z};
+    bool own = true;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t k = (desc >> (10 * r)) & 31u, pm1 = (desc >> (10 * r + 5)) & 31u;
+        const float fp = (float)(pm1 + 1u);
+        const float c = floorf((y[r] * inv + 0.5f) * fp); // cell index before clamping (NaN compares false below: no owner)
+        const float ck = fminf(fmaxf(c, 0.0f), (float)pm1);
+        own = own && (ck == (float)k);
+    }
+    return own;
+}
+
 // computeResponse — shaders/tracer.cuh:187-214, given o_g = A(o-mu), d_g = A d already formed
 __device__ __forceinline__ float response_from(const m33& A, f3 mu, f3 o, f3 d, f3 o_g, f3 d_g)
 {

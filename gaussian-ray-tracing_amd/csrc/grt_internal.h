@@ -74,6 +74,7 @@ struct RenderArgs {
     const float4* pbox;   // [n_prox*2] per-proxy boxes in sorted order (tile kernel)
     uint32_t root_ref;
     uint32_t n_prox;
+    uint32_t has_pieces;  // the tree's leaves include pieces of split proxies (the record's last word is the cell descriptor)
     const float4* color0; // [n_particles] degree-0 radiance by ORIGINAL particle id
     const float* sh;      // [n_particles][16][3] by original id
     // mesh scene
@@ -211,6 +212,8 @@ struct grt_ctx {
     int opt_swizzle = 2;
     int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24, opt_tile_prio = 0; // band / look in 1/1024
     int opt_size_classes = 1;
+    int opt_split = 8;            // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off)
+    uint32_t n_hittable = 0;      // particles with opacity > alpha_min (BVH primitives = these, or their pieces)
     float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags
     uint32_t* d_ovf_next = nullptr;
     uint32_t ovf_chunks = 0;
@@ -222,6 +225,7 @@ struct grt_ctx {
     bool ovf_pending = false;
     uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
+    uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)
     hipStream_t tail_stream = nullptr; // stream the post-frame work (next order, zeroing) was queued on
     hipEvent_t ev_tail = nullptr;

@@ -42,6 +42,7 @@ __device__ __forceinline__ void kbuf_insert(KBuf<KK>& kb, uint64_t key, float al
     if (key >= kb.key[KK - 1]) return;
 #pragma unroll
     for (int i = 0; i < KK; i++) {
+        if (key == kb.key[i]) return; // the same event again: a split particle met through another of its pieces
         if (key < kb.key[i]) {
             const uint64_t tk = kb.key[i];
             const float ta = kb.alpha[i];
@@ -87,8 +88,10 @@ __device__ __forceinline__ bool gps_round(const RenderArgs& a, uint32_t* __restr
                 const f3 d_g = matvec(A, d);
                 float te, tx;
                 if (proxy_sphere_maybe(o_g, d_g, r0.w) && proxy_slabs(o_g, d_g, r0.w, te, tx)) {
-                    const bool in_e = (te >= t_lo) && (te < t_hi);
-                    const bool in_x = (tx >= t_lo) && (tx < t_hi);
+                    // (a piece of a split proxy reports an event only when the event's point lies in its cell)
+                    const uint32_t cellb = __float_as_uint(r3.w);
+                    const bool in_e = (te >= t_lo) && (te < t_hi) && (!cellb || piece_owns(cellb, r0.w, o_g, d_g, te));
+                    const bool in_x = (tx >= t_lo) && (tx < t_hi) && (!cellb || piece_owns(cellb, r0.w, o_g, d_g, tx));
                     if (in_e || in_x) {
                         // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357):
                         // evaluated once, carried by the entry and the exit hit

@@ -230,7 +230,11 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // small mesh tree in step on the idle overflow stack) and goes on with the next iteration of the bounce loop.  The same
 // mode finishes the rays of the retry queue (a.single_own_mesh: per-lane segments that went over their budget).
 // Same arithmetic per event, same order: same bits.
-template <bool COUNT, bool SH, bool MESH, int MODE>
+// PIECES = true: the tree holds pieces of split proxies (grt_api.hip: k_piece_boxes) — a piece reports a particle only when
+// the lane's first pending event lies in its cell, and the repeats that are still possible are dropped.  Scenes without
+// pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
+// instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
+template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
 __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_tile(const RenderArgs a)
 {
     constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
@@ -644,14 +648,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                         SLOT_SHIFT_ALL(om)
                         ea = lane_value(ea, ol); eo = lane_value(eo, ol);
                         cr = lane_value(cr, ol); cg = lane_value(cg, ol); cb = lane_value(cb, ol);
-                        if (COUNT && tally) c.hit_evals++;
+                        const bool dup_ = PIECES && ((ek | kCellMask) == last_key); // the same event again (another piece of a split particle)
+                        if (COUNT && tally && !dup_) c.hit_evals++;
                         last_key = ek | kCellMask;
-                        if (a.p.alpha_min < ea) { // shaders/tracer.cuh:352-367
+                        if (!dup_ && a.p.alpha_min < ea) { // shaders/tracer.cuh:352-367
                             radiance = add3(radiance, mul3s(mul3s(mk3(cr, cg, cb), T), ea));
                             T *= (1.0f - ea);
                         }
                         if (!(T > minT)) alive = false;
-                        const bool rekey = own && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
+                        const bool rekey = own && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
                         const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
                         pmask = (own && !rekey) ? (pmask & ~(1u << cell)) : pmask;
                         if (wave_any(rekey)) { // wave-uniform branch
@@ -740,7 +745,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                             dbg_n++;
                         }
 #endif
-                        if (can_) { // shaders/tracer.cuh:352-367
+                        // equal keys meet in the window when a split particle was inserted through two of its pieces: the first is
+                        // composited, the repeat only gives its cell back
+                        const bool dup_ = PIECES && can_ && ((ek | kCellMask) == last_key);
+                        if (can_ && !dup_) { // shaders/tracer.cuh:352-367
                             if (COUNT) c.hit_evals++;
                             last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
                             if (a.p.alpha_min < ea) {
@@ -759,7 +767,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                         }
                         // an entry whose exit lies inside the segment is re-keyed to its exit event and keeps its
                         // payload cell, otherwise the cell is released
-                        const bool rekey = can_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
+                        const bool rekey = can_ && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
                         const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
                         pmask = (can_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
                         if (wave_any(rekey)) { // wave-uniform branch
@@ -970,8 +978,18 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
                         const uint32_t id = __float_as_uint(r2.w);
                         const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
                         // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
-                        const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > pass_lo);
-                        const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > pass_lo);
+                        // (> last_key, not just > pass_lo: a particle that entered the tree as several pieces is met once per
+                        //  piece the tile crosses, with the same keys; what was composited already is not taken again)
+                        const uint64_t seen_ = PIECES ? last_key : pass_lo;
+                        bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > seen_);
+                        bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > seen_);
+                        const uint32_t cellb = PIECES ? __float_as_uint(r3.w) : 0u;
+                        if (PIECES && cellb) { // a piece of a split proxy (wave-uniform but in MODE 2): it reports the particle only when the
+                                     // lane's first pending event lies in ITS cell (piece_owns, grt_device.h)
+                            const bool own_ = piece_owns(cellb, r0.w, o_g, d_g, in_e ? te : tx);
+                            in_e = in_e && own_;
+                            in_x = in_x && own_;
+                        }
                         const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
                         const bool ins = (k_first != kKeyInvalid) && (k_first < lost);
 #ifdef GRT_TILE_CHECK
@@ -1213,13 +1231,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
 } // namespace
 
 typedef void (*TileKernel)(const RenderArgs);
-static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode)
+static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode, bool pieces)
 {
-#define GRT_PICK2(C, S)                                                                                    \
-    (mode == 2 ? k_render_tile<C, S, true, 2> : (mode == 1 ? k_render_tile<C, S, true, 1>                  \
-               : (mesh ? k_render_tile<C, S, true, 0> : k_render_tile<C, S, false, 0>)))
+#define GRT_PICK3(C, S, P)                                                                                 \
+    (mode == 2 ? k_render_tile<C, S, true, 2, P> : (mode == 1 ? k_render_tile<C, S, true, 1, P>            \
+               : (mesh ? k_render_tile<C, S, true, 0, P> : k_render_tile<C, S, false, 0, P>)))
+#define GRT_PICK2(C, S) (pieces ? GRT_PICK3(C, S, true) : GRT_PICK3(C, S, false))
     return count ? (sh ? GRT_PICK2(true, true) : GRT_PICK2(true, false)) : (sh ? GRT_PICK2(false, true) : GRT_PICK2(false, false));
 #undef GRT_PICK2
+#undef GRT_PICK3
 }
 
 // mode 0: camera rays (mesh = stage 2 of the wavefront pipeline: up to their mesh hit); mode 1: stage 3, one wave per
@@ -1241,7 +1261,7 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
     RenderArgs b = a;
     b.heavy_role = 0;
     const uint32_t grid = (mode == 2) ? 2048u : a.n_blocks * 4u; // mode 2: 8 waves per CU are resident (19 KB of LDS each)
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode), dim3(grid), dim3(kWG), 0, stream, b);
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, stream, b);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("k_render_tile launch: ") + hipGetErrorString(e);

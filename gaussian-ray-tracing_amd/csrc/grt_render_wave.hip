@@ -53,6 +53,15 @@ __device__ __forceinline__ void kbuf_insert(KBuf& kb, uint64_t key, float alpha)
     }
 }
 
+// is the event already buffered?  (a split particle is met once per piece the ray's tile crosses, with the same keys)
+__device__ __forceinline__ bool kbuf_has(const KBuf& kb, uint64_t key)
+{
+    bool h = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) h = h || (kb.key[i] == key);
+    return h;
+}
+
 // scalar (SGPR) fetch of one float4 at a wave-uniform index: constant address space => s_load_dwordx4
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 sload4(const float4* base, uint32_t idx)
@@ -111,8 +120,11 @@ __device__ __forceinline__ void gps_round_wave(const RenderArgs& a, f3 o, f3 d, 
                 const uint32_t id = __float_as_uint(r2.w);
                 const uint64_t ke = mk_key(te, id, 0), kx = mk_key(tx, id, 1);
                 // te/tx may be negative or NaN: the float compares gate the (unsigned) key compares
-                const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > last_key) && (ke < kb.key[K - 1]);
-                const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > last_key) && (kx < kb.key[K - 1]);
+                const uint32_t cellb = __float_as_uint(r3.w); // piece of a split proxy: an event belongs to the cell its point lies in
+                const bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > last_key) && (ke < kb.key[K - 1]) && !kbuf_has(kb, ke) &&
+                                  (!cellb || piece_owns(cellb, r0.w, o_g, d_g, te));
+                const bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > last_key) && (kx < kb.key[K - 1]) && !kbuf_has(kb, kx) &&
+                                  (!cellb || piece_owns(cellb, r0.w, o_g, d_g, tx));
                 if (__any(in_e || in_x)) { // wave-uniform branch
                     // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
                     const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);

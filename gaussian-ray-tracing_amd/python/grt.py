@@ -37,7 +37,8 @@ class Counters(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_particles", C.c_uint64), ("n_proxies", C.c_uint64), ("n_nodes", C.c_uint32),
                 ("height", C.c_uint32), ("mesh_faces", C.c_uint32), ("mesh_height", C.c_uint32),
-                ("build_ms", C.c_float), ("mesh_update_ms", C.c_float), ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3)]
+                ("build_ms", C.c_float), ("mesh_update_ms", C.c_float), ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3),
+                ("n_primitives", C.c_uint64)]
 
 
 class MemoryInfo(C.Structure):
@@ -58,7 +59,7 @@ MIRROR, NORMAL, GLASS = 0, 1, 2
 OPT_COUNTERS, OPT_KERNEL, OPT_LEAF_MAX, OPT_SWIZZLE, OPT_FEEDBACK = 1, 2, 3, 4, 5
 OPT_TILE_READY_MIN, OPT_TILE_BAND, OPT_TILE_LOOKAHEAD, OPT_TILE_RESERVE, OPT_TILE_PRIO_DIV, OPT_COST_RADIUS, OPT_SIZE_CLASSES, OPT_COLD_ESTIMATE = 8, 9, 10, 11, 12, 13, 14, 15
 OPT_BUNDLE_ROUNDS, OPT_BUNDLE_BUDGET, OPT_SINGLE_LOOKAHEAD, OPT_SINGLE_BAND, OPT_LANE_BUDGET = 16, 17, 18, 19, 20
-OPT_OVF_CHUNKS, OPT_OVF_ENTRIES, OPT_MAX_ITERS = 21, 22, 23
+OPT_OVF_CHUNKS, OPT_OVF_ENTRIES, OPT_MAX_ITERS, OPT_SPLIT = 21, 22, 23, 24
 ERR_LIMIT = -5
 KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERNEL_TILE = 0, 1, 2, 3, 4, 5
 

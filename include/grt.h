@@ -111,7 +111,7 @@ typedef struct {
 
 typedef struct {
     uint64_t n_particles;   /* uploaded */
-    uint64_t n_proxies;     /* hittable (opacity > alpha_min) */
+    uint64_t n_proxies;     /* hittable particles (opacity > alpha_min) */
     uint32_t n_nodes;       /* internal nodes of the Gaussian LBVH */
     uint32_t height;        /* LBVH height (levels of internal nodes) */
     uint32_t mesh_faces;
@@ -119,6 +119,8 @@ typedef struct {
     float build_ms;         /* device time of the last grt_build_bvh */
     float mesh_update_ms;   /* device time of the last grt_set_meshes (build) / grt_update_meshes (refit) */
     float scene_lo[3], scene_hi[3];
+    uint64_t n_primitives;  /* leaves of the Gaussian LBVH: the hittable particles, large anisotropic ones as several pieces
+                               (GRT_OPT_SPLIT) */
 } grt_bvh_info;
 
 typedef struct {
@@ -166,6 +168,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          1024, doubled for GRT_GLASS.  Same image for every value */,
        GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 256 = 25 %) */,
        GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
+       GRT_OPT_SPLIT = 24             /* spatial splits: a proxy much longer than the typical one whose world box is mostly empty (a needle or
+                                         sheet that is not axis-aligned) enters the LBVH as up to 512 pieces, each with the box of its cell;
+                                         value = piece length in quarters of the geometric-mean proxy diagonal (default 8 = 2 x; 0 = off).
+                                         Pure acceleration structure: same hits, same pixels.  Per context; next build */,
        /* testing knobs (frames never change; speed and the failure signal do) */
        GRT_OPT_OVF_CHUNKS = 21        /* tile kernel's pool of window-overflow bags: 0 (default) = sized from the demand of the
                                          frames before; n > 0: exactly n chunks; < 0: no pool (every overflow costs another pass) */,
