@@ -60,6 +60,12 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #ifndef GRT_TILE_WAVES
 #define GRT_TILE_WAVES 4
 #endif
+#ifndef GRT_TILE_WAVES1
+#define GRT_TILE_WAVES1 GRT_TILE_WAVES /* ... the bundle kernel (MODE 1) */
+#endif
+#ifndef GRT_TILE_WAVES0
+#define GRT_TILE_WAVES0 GRT_TILE_WAVES /* waves per SIMD the camera-ray kernel without meshes is compiled for */
+#endif
 #ifndef GRT_BISECT
 #define GRT_BISECT 18 /* most bisection steps of a nearest-k selection (4 / 6 at least) */
 #endif
@@ -69,10 +75,31 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #ifndef GRT_RF_ROOM
 #define GRT_RF_ROOM k8 /* a lane with room above this slot joins a refill scan it does not need yet */
 #endif
-#define GRT_KS 12
-#define KS 12
+#ifndef GRT_TILE_KS
+#define GRT_TILE_KS 12 /* keys of a lane's sorted window: 12, or 8 */
+#endif
+#define GRT_KS GRT_TILE_KS
+#define KS GRT_TILE_KS
+#if GRT_TILE_KS == 12
 #define KLAST k11
 #define KPRESS k9 /* a lane holding >= KS-2 keys asks for compositing before the next insert */
+#define GRT_KEYS_DECL                                                                                      \
+    uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,     \
+             k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid, k8 = kKeyInvalid, k9 = kKeyInvalid,     \
+             k10 = kKeyInvalid, k11 = kKeyInvalid;
+#define GRT_KEYS_RESET k0 = k1 = k2 = k3 = k4 = k5 = k6 = k7 = k8 = k9 = k10 = k11 = kKeyInvalid;
+#elif GRT_TILE_KS == 8
+#define KLAST k7
+#define KPRESS k5
+#undef GRT_RF_ROOM
+#define GRT_RF_ROOM k4
+#define GRT_KEYS_DECL                                                                                      \
+    uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,     \
+             k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid;
+#define GRT_KEYS_RESET k0 = k1 = k2 = k3 = k4 = k5 = k6 = k7 = kKeyInvalid;
+#else
+#error "GRT_TILE_KS must be 8 or 12"
+#endif
 #include "grt_slots_gen.inc"
 #define PL_OTHER(cell) pl_other[(cell) * kWG + lane]
 #define PL_ALPHA(cell) pl_alpha[(cell) * kWG + lane]
@@ -235,7 +262,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
 // instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
 template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
-__global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_tile(const RenderArgs a)
+__global__ __launch_bounds__(kWG, MODE == 2 ? 2 : (MODE == 1 ? GRT_TILE_WAVES1 : (MODE == 0 && !MESH ? GRT_TILE_WAVES0 : GRT_TILE_WAVES))) void k_render_tile(const RenderArgs a)
 {
     constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
     const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
@@ -443,9 +470,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
         uint64_t last_key = mk_skey(a.p.t_min + epsT, 0x03FFFFFFu, 1) | kCellMask; // last composited event (exclusive bound)
         bool alive = have_ray && (T > minT);
         uint32_t stalls = 0;
-        uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,
-                 k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid, k8 = kKeyInvalid, k9 = kKeyInvalid,
-                 k10 = kKeyInvalid, k11 = kKeyInvalid;
+        GRT_KEYS_DECL
         uint32_t pmask = 0; // payload cells in use
         uint32_t iters = 0; // wave-uniform work measure for the scheduling feedback
         uint32_t work = 0;  // MODE 1: particles fetched + 2 x exact tests run (wave-uniform), against the budget
@@ -481,7 +506,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : GRT_TILE_WAVES) void k_render_
             uint64_t lost = kKeyInvalid;   // smallest key this lane had to drop for good in this pass
             uint32_t nb = 0;               // entries in this lane's bag
             bool bags = false;             // some lane has a non-empty bag (wave-uniform)
-            k0 = k1 = k2 = k3 = k4 = k5 = k6 = k7 = k8 = k9 = k10 = k11 = kKeyInvalid;
+            GRT_KEYS_RESET
             pmask = 0;
             // wave-level interval of interest: nothing beyond LIM, nothing that ends before LO (stale values are
             // conservative: LIM only shrinks, LO only grows)

@@ -29,7 +29,8 @@ GaussianTracer::~GaussianTracer()
 
 void GaussianTracer::initializeOptix() // src/GaussianTracer.cpp:72-83
 {
-    if (grt_create(&m_ctx, 0) != GRT_OK) throw std::runtime_error(grt_last_error(nullptr));
+    hipglue::setDevice(m_device);
+    if (grt_create(&m_ctx, m_device) != GRT_OK) throw std::runtime_error(grt_last_error(nullptr));
     createGaussianParticlesBVH();
     initializeParams();
 }
@@ -74,6 +75,19 @@ void GaussianTracer::render(CUDAOutputBuffer& output_buffer) // src/GaussianTrac
     uchar3* result = output_buffer.map();
     params.output_buffer = result;
     grt_params p{};
+    fillParams(&p);
+    check(grt_render(m_ctx, &p, reinterpret_cast<uint8_t*>(result), nullptr, 0, 0, params.width, params.height, stream), "grt_render");
+    output_buffer.unmap();
+    hipglue::streamSync(stream); // CUDA_SYNC_CHECK, :537
+    // the frame is done: a wave that had to give up on live rays (watchdog, stack guard, stalled passes) left its reason
+    // in the context's sticky error word — thrown here, as OptiX exceptions are in the reference (:114-119, Exception.h:31-80)
+    check(grt_sync(m_ctx), "render");
+}
+
+void GaussianTracer::fillParams(void* out) const // Params (src/Parameters.h:42-74) -> the C ABI's grt_params
+{
+    grt_params& p = *static_cast<grt_params*>(out);
+    p = grt_params{};
     p.width = params.width; p.height = params.height; p.sh_degree_max = params.sh_degree_max;
     p.eye[0] = params.eye.x; p.eye[1] = params.eye.y; p.eye[2] = params.eye.z;
     p.U[0] = params.U.x; p.U[1] = params.U.y; p.U[2] = params.U.z;
@@ -83,11 +97,31 @@ void GaussianTracer::render(CUDAOutputBuffer& output_buffer) // src/GaussianTrac
     p.mode_fisheye = params.mode_fisheye ? 1 : 0;
     p.type = params.type;
     p.max_bounces = params.max_bounces;
-    check(grt_render(m_ctx, &p, reinterpret_cast<uint8_t*>(result), nullptr, 0, 0, params.width, params.height, stream), "grt_render");
+}
+
+void GaussianTracer::renderTiles(unsigned char* d_tiles, unsigned int tile_w, unsigned int tile_h, unsigned int first,
+                                 unsigned int stride, unsigned int count)
+{
+    hipglue::setDevice(m_device);
+    grt_params p{};
+    fillParams(&p);
+    check(grt_render_tiles(m_ctx, &p, d_tiles, nullptr, tile_w, tile_h, first, stride, count, stream), "grt_render_tiles");
+}
+
+void GaussianTracer::assembleTiles(const unsigned char* d_gathered, unsigned int world, unsigned int max_count, unsigned int tile_w,
+                                   unsigned int tile_h, CUDAOutputBuffer& output_buffer)
+{
+    hipglue::setDevice(m_device);
+    uchar3* result = output_buffer.map();
+    check(grt_assemble_tiles(m_ctx, d_gathered, world, max_count, tile_w, tile_h, params.width, params.height,
+                             reinterpret_cast<uint8_t*>(result), stream), "grt_assemble_tiles");
     output_buffer.unmap();
-    hipglue::streamSync(stream); // CUDA_SYNC_CHECK, :537
-    // the frame is done: a wave that had to give up on live rays (watchdog, stack guard, stalled passes) left its reason
-    // in the context's sticky error word — thrown here, as OptiX exceptions are in the reference (:114-119, Exception.h:31-80)
+}
+
+void GaussianTracer::sync()
+{
+    hipglue::setDevice(m_device);
+    hipglue::streamSync(stream);
     check(grt_sync(m_ctx), "render");
 }
 

@@ -46,6 +46,17 @@ public:
     // extras for headless use
     float lastKernelMs();
     grt_ctx* context() { return m_ctx; }
+    // one tracer per GPU (the CLI's --gpus N): the device this tracer's scene lives on (before
+    // initializeOptix), and the tracer's share of a frame — tiles first + j * stride (j < count) of the tile_w x tile_h
+    // grid into the compact device buffer [count][tile_h][tile_w][3] (asynchronous on `stream`)
+    void setDevice(int device) { m_device = device; }
+    int device() const { return m_device; }
+    void renderTiles(unsigned char* d_tiles, unsigned int tile_w, unsigned int tile_h, unsigned int first, unsigned int stride,
+                     unsigned int count);
+    // rank 0: the ranks' compact buffers [world][max_count][tile_h][tile_w][3] (device memory of this tracer's GPU) -> frame
+    void assembleTiles(const unsigned char* d_gathered, unsigned int world, unsigned int max_count, unsigned int tile_w,
+                       unsigned int tile_h, CUDAOutputBuffer& output_buffer);
+    void sync(); // waits for this tracer's stream and throws when a wave had to give up on live rays (grt_sync)
 
 private:
     void initializeParams();
@@ -54,7 +65,10 @@ private:
     float3 primitivePosition() const;
     void check(int rc, const char* what);
 
+    // (void*: grt_params by value would drag include/grt.h into this header)
+    void fillParams(void* grt_params_out) const;
     grt_ctx* m_ctx = nullptr;
+    int m_device = 0;
     GaussianData m_gsData;
     size_t particle_count;
     float alpha_min;

@@ -12,4 +12,8 @@ void  copyToHost(void* dst, const void* src, size_t bytes);
 void* hostAllocPinned(size_t bytes);
 void  hostFreePinned(void* p);
 void  copyToHostAsync(void* dst, const void* src, size_t bytes, void* stream);
+// several GPUs in one process (the CLI's --gpus N: one GaussianTracer per device, each driven by its own host thread)
+int   deviceCount();
+void  setDevice(int device);
+void  copyPeerAsync(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
 }

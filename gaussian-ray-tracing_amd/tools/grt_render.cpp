@@ -2,7 +2,8 @@
 // (src/main.cpp:9-131) on a display-less MI355X: same flags -p/--ply, --width, --height and the same
 // defaults (src/main.cpp:62-66: ../data/train.ply, 1280x720), the same call sequence
 // (tracer.setSize -> initializeOptix -> camera init (src/gui.cpp:50-67) -> updateCamera -> render),
-// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png|frame.npy --bench N.
+// plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png|frame.npy --bench N
+// --gpus N (tile-sharded over N GPUs of the node: one tracer and one host thread per GPU, peer copies to the first).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -10,11 +11,14 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../host/Display.h"
 #include "../host/GaussianTracer.h"
+#include "../host/HipGlue.h"
 
 // Minimal PNG writer (8-bit RGB, stored deflate blocks: no compression library needed; CRC-32 and Adler-32 per the
 // PNG / zlib specifications)
@@ -92,7 +96,10 @@ static void usage()
     std::puts("usage: grt_render [-p|--ply scene.ply] [--width W] [--height H] [--fisheye] [--type mirror|normal|glass]\n"
               "                  [--sh-degree 0..3] [--plane] [--sphere] [--obj mesh.obj] [--bounces N]\n"
               "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png|frame.npy] [--raw frame.rgb]\n"
-              "                  [--move dx dy dz] [--bench N]");
+              "                  [--move dx dy dz] [--bench N] [--gpus N] [--devices d0,d1,...]\n"
+              "  --gpus N: the frame's 32x32 tiles are dealt round-robin to N GPUs of this node (one GaussianTracer and one host\n"
+              "            thread per GPU, scene replicated), the tile buffers are copied to the first GPU over xGMI and un-permuted\n"
+              "            there.  --devices names the GPUs (default 0..N-1; a device may repeat: ranks then share it).");
 }
 
 int main(int argc, char** argv)
@@ -102,7 +109,8 @@ int main(int argc, char** argv)
     bool have_move = false;
     unsigned int width = 1280, height = 720, sh_degree = 0, bounces = 32;
     bool fisheye = false, plane = false, sphere = false;
-    int type = MIRROR, bench = 0;
+    int type = MIRROR, bench = 0, gpus = 1;
+    std::vector<int> devices;
     float eye[3] = {0.0f, 0.0f, 3.0f}, fov = 60.0f;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -123,6 +131,11 @@ int main(int argc, char** argv)
         else if (a == "--raw") { need(1); raw_out = argv[++i]; }
         else if (a == "--move") { need(3); for (int k = 0; k < 3; k++) move[k] = (float)std::atof(argv[++i]); have_move = true; }
         else if (a == "--bench") { need(1); bench = std::atoi(argv[++i]); }
+        else if (a == "--gpus") { need(1); gpus = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--devices") {
+            need(1);
+            for (const char* q = argv[++i]; *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
+        }
         else if (a == "--type") {
             need(1);
             const std::string t = argv[++i];
@@ -131,48 +144,97 @@ int main(int argc, char** argv)
         } else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); usage(); return 2; }
     }
     try {
-        GaussianTracer tracer(ply);
-        tracer.setSize(width, height);
-        tracer.initializeOptix();
-        tracer.params.sh_degree_max = sh_degree;
-        tracer.params.mode_fisheye = fisheye;   // gui.cpp:433
-        tracer.params.max_bounces = bounces;
-        tracer.setRenderType((unsigned)type);   // gui.cpp:178-184
-
-        Camera camera;                          // GUI::initCamera, src/gui.cpp:50-67
-        camera.setEye(make_float3(eye[0], eye[1], eye[2]));
-        camera.setLookat(tracer.getGaussianCenter());
-        camera.setUp(make_float3(0.0f, 1.0f, 0.0f));
-        camera.setFovY(fov);
-        bool camera_changed = true;
-        tracer.updateCamera(camera, camera_changed);
-        if (plane) tracer.createPlane();        // gui.cpp:170
-        if (sphere) tracer.createSphere();      // gui.cpp:173
-        if (!obj.empty()) tracer.createLoadMesh(obj);
-        if (have_move && !tracer.getPrimitives().empty()) { // a gizmo drag of the last primitive (src/gui.cpp:430-433)
-            Primitive& pr = tracer.getPrimitives().back();
-            pr.transform.m[3][0] += move[0]; pr.transform.m[3][1] += move[1]; pr.transform.m[3][2] += move[2];
-            tracer.updateInstanceTransforms(pr);
+        if (devices.empty()) for (int k = 0; k < gpus; k++) devices.push_back(k);
+        gpus = (int)devices.size();
+        // one tracer per rank (rank 0 is the one the frame ends up on); each goes through the reference's call sequence
+        std::vector<std::unique_ptr<GaussianTracer>> tracers;
+        for (int k = 0; k < gpus; k++) {
+            tracers.emplace_back(new GaussianTracer(ply));
+            GaussianTracer& t = *tracers.back();
+            t.setDevice(devices[(size_t)k]);
+            t.setSize(width, height);
         }
-
+        auto per_rank = [&](auto&& fn) { // ranks in parallel, one host thread each; the first exception is re-thrown
+            std::vector<std::thread> th;
+            std::vector<std::string> errs((size_t)gpus);
+            for (int k = 0; k < gpus; k++)
+                th.emplace_back([&, k] { try { fn(k, *tracers[(size_t)k]); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); if (errs[(size_t)k].empty()) errs[(size_t)k] = "error"; } });
+            for (auto& t : th) t.join();
+            for (int k = 0; k < gpus; k++) if (!errs[(size_t)k].empty()) throw std::runtime_error("rank " + std::to_string(k) + ": " + errs[(size_t)k]);
+        };
+        per_rank([&](int, GaussianTracer& t) {
+            t.initializeOptix();
+            t.params.sh_degree_max = sh_degree;
+            t.params.mode_fisheye = fisheye;   // gui.cpp:433
+            t.params.max_bounces = bounces;
+            t.setRenderType((unsigned)type);   // gui.cpp:178-184
+            Camera camera;                     // GUI::initCamera, src/gui.cpp:50-67
+            camera.setEye(make_float3(eye[0], eye[1], eye[2]));
+            camera.setLookat(t.getGaussianCenter());
+            camera.setUp(make_float3(0.0f, 1.0f, 0.0f));
+            camera.setFovY(fov);
+            bool camera_changed = true;
+            t.updateCamera(camera, camera_changed);
+            if (plane) t.createPlane();        // gui.cpp:170
+            if (sphere) t.createSphere();      // gui.cpp:173
+            if (!obj.empty()) t.createLoadMesh(obj);
+            if (have_move && !t.getPrimitives().empty()) { // a gizmo drag of the last primitive (src/gui.cpp:430-433)
+                Primitive& pr = t.getPrimitives().back();
+                pr.transform.m[3][0] += move[0]; pr.transform.m[3][1] += move[1]; pr.transform.m[3][2] += move[2];
+                t.updateInstanceTransforms(pr);
+            }
+        });
+        GaussianTracer& tracer = *tracers[0];
+        hipglue::setDevice(tracer.device());
         CUDAOutputBuffer output_buffer(width, height); // = HIPOutputBuffer (src/main.cpp:77)
         output_buffer.setStream(tracer.stream);
-        tracer.render(output_buffer);
+
+        // ---- N > 1: tile t of the row-major 32x32 grid belongs to rank t % N (its tile t / N), as in bench.py ----
+        const unsigned int TILE = 32, tiles_x = (width + TILE - 1) / TILE, tiles_y = (height + TILE - 1) / TILE;
+        const unsigned int n_tiles = tiles_x * tiles_y, max_cnt = (n_tiles + (unsigned)gpus - 1) / (unsigned)gpus;
+        const size_t tile_bytes = (size_t)TILE * TILE * 3;
+        std::vector<unsigned char*> mine((size_t)gpus, nullptr);
+        unsigned char* gathered = nullptr;
+        if (gpus > 1) {
+            for (int k = 0; k < gpus; k++) {
+                hipglue::setDevice(devices[(size_t)k]);
+                mine[(size_t)k] = static_cast<unsigned char*>(hipglue::deviceAlloc(max_cnt * tile_bytes));
+            }
+            hipglue::setDevice(tracer.device());
+            gathered = static_cast<unsigned char*>(hipglue::deviceAlloc((size_t)gpus * max_cnt * tile_bytes));
+        }
+        auto frame = [&] {
+            if (gpus == 1) { tracer.render(output_buffer); return; }
+            per_rank([&](int k, GaussianTracer& t) {
+                const unsigned int cnt = (n_tiles > (unsigned)k) ? (n_tiles - (unsigned)k + (unsigned)gpus - 1) / (unsigned)gpus : 0u;
+                t.renderTiles(mine[(size_t)k], TILE, TILE, (unsigned)k, (unsigned)gpus, cnt);
+                // the rank's compact buffer -> its slice of rank 0's gather buffer (peer copy over xGMI), behind the render
+                hipglue::copyPeerAsync(gathered + (size_t)k * max_cnt * tile_bytes, tracer.device(), mine[(size_t)k], t.device(),
+                                       (size_t)cnt * tile_bytes, t.stream);
+                t.sync();
+            });
+            tracer.assembleTiles(gathered, (unsigned)gpus, max_cnt, TILE, TILE, output_buffer);
+            tracer.sync();
+        };
+        frame();
         if (bench > 0) {
-            for (int i = 0; i < 3; i++) tracer.render(output_buffer);
+            for (int i = 0; i < 3; i++) frame();
             std::vector<double> ms;
             double kms = 0.0;
             for (int i = 0; i < bench; i++) {
                 const auto t0 = std::chrono::steady_clock::now();
-                tracer.render(output_buffer);   // includes the device sync, like the reference's render timer
+                frame();   // includes the device sync, like the reference's render timer
                 ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 kms += tracer.lastKernelMs();
             }
             std::sort(ms.begin(), ms.end());
             const double med = ms[ms.size() / 2];
-            std::printf("frames %d  median %.3f ms/frame  kernel %.3f ms  %.1f Mrays/s (primary)\n", bench, med, kms / bench,
-                        (double)width * height / med / 1e3);
+            std::printf("frames %d  median %.3f ms/frame  kernel %.3f ms%s  %.1f Mrays/s (primary)  gpus %d\n", bench, med, kms / bench,
+                        gpus > 1 ? " (rank 0)" : "", (double)width * height / med / 1e3, gpus);
         }
+        for (int k = 0; k < gpus; k++) { if (mine[(size_t)k]) { hipglue::setDevice(devices[(size_t)k]); hipglue::deviceFree(mine[(size_t)k]); } }
+        hipglue::setDevice(tracer.device());
+        hipglue::deviceFree(gathered);
         if (!raw_out.empty()) { // the buffer as the renderer wrote it (row 0 first), from the pinned mirror render() filled
             std::ofstream f(raw_out, std::ios::binary);
             f.write(reinterpret_cast<const char*>(output_buffer.getHostPointer()), (std::streamsize)((size_t)width * height * 3));

@@ -158,3 +158,21 @@ def test_cli_viewer_glue_row_zero_is_the_bottom_and_drag_refits(tmp_path):
     assert bad <= 2e-3, bad  # float association of (v + pos) + move may differ by an ulp from the facade's matrix product
     top, bottom = buf[H - 8:].astype(int).sum(), buf[:8].astype(int).sum()
     assert top != bottom  # the frame is not symmetric: the orientation check above has teeth
+
+
+@pytest.mark.gpu
+def test_cli_gpus_n_tile_sharded_frame_equals_the_one_gpu_frame(tmp_path):
+    """--gpus N: one GaussianTracer and one host thread per rank, the frame's 32x32 tiles dealt
+    round-robin, peer copies of the compact tile buffers to rank 0, un-permute there.  On a one-GPU box the ranks share
+    device 0 (--devices 0,0,0): the assembled frame must be the one-launch frame byte for byte (ragged frame, 3 ranks,
+    mirror sphere)."""
+    ply, acts = _scene(tmp_path)
+    one, three = str(tmp_path / "one.npy"), str(tmp_path / "three.npy")
+    common = [CLI, "-p", ply, "--width", "200", "--height", "136", "--type", "mirror", "--sphere", "--bounces", "3"]
+    r = subprocess.run(common + ["--out", one], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(common + ["--out", three, "--gpus", "3", "--devices", "0,0,0", "--bench", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "gpus 3" in r.stdout
+    a, b = np.load(one), np.load(three)
+    assert a.shape == (136, 200, 3) and a.any() and (a == b).all()
