@@ -151,6 +151,7 @@ int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std:
 int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
                          std::string* err);
 int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err);
+int launch_render_tile_single(const RenderArgs& a, bool count, hipStream_t stream, std::string* err); // mode 2 (its own TU)
 constexpr int kNumCounters = 8;
 // bits of RenderArgs::err_word
 constexpr uint32_t kErrWatchdog = 1u, kErrStack = 2u, kErrStall = 4u;

@@ -60,6 +60,9 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #ifndef GRT_TILE_WAVES
 #define GRT_TILE_WAVES 4
 #endif
+#ifndef GRT_TILE_WAVES2
+#define GRT_TILE_WAVES2 2 /* ... the one-ray-per-wave kernel (MODE 2; 19 KB of LDS per wave at 12 keys: 8 waves per CU) */
+#endif
 #ifndef GRT_TILE_WAVES1
 #define GRT_TILE_WAVES1 GRT_TILE_WAVES /* ... the bundle kernel (MODE 1) */
 #endif
@@ -262,7 +265,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
 // instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
 template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
-__global__ __launch_bounds__(kWG, MODE == 2 ? 2 : (MODE == 1 ? GRT_TILE_WAVES1 : (MODE == 0 && !MESH ? GRT_TILE_WAVES0 : GRT_TILE_WAVES))) void k_render_tile(const RenderArgs a)
+__global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT_TILE_WAVES1 : (MODE == 0 && !MESH ? GRT_TILE_WAVES0 : GRT_TILE_WAVES))) void k_render_tile(const RenderArgs a)
 {
     constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
     const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
@@ -1256,11 +1259,37 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? 2 : (MODE == 1 ? GRT_TILE_WAVES1 :
 } // namespace
 
 typedef void (*TileKernel)(const RenderArgs);
+#ifdef GRT_TILE_SINGLE_TU
+// ---- this translation unit (grt_render_tile_single.hip) holds the one-ray-per-wave mode alone, compiled with an 8-key
+//      window: its LDS per wave is 14 KB instead of 19 KB (the window's payload cells carry the events' radiance there) and
+//      it fits 168 VGPRs, so 11 waves per CU are resident instead of 8.  The mode waits on memory for 46 % of its wave
+//      cycles (profiles/r03_C4_counters.json): C4 3.98 -> 3.82 ms.  The camera-ray and bundle kernels keep 12 keys (with 8
+//      they lose 4-10 %). ----
+static TileKernel pick_single(bool count, bool sh, bool pieces)
+{
+#define GRT_PICK2(C, S) (pieces ? k_render_tile<C, S, true, 2, true> : k_render_tile<C, S, true, 2, false>)
+    return count ? (sh ? GRT_PICK2(true, true) : GRT_PICK2(true, false)) : (sh ? GRT_PICK2(false, true) : GRT_PICK2(false, false));
+#undef GRT_PICK2
+}
+
+int launch_render_tile_single(const RenderArgs& a, bool count, hipStream_t stream, std::string* err)
+{
+    const bool sh = a.p.sh_degree_max > 0;
+    RenderArgs b = a;
+    b.heavy_role = 0;
+    hipLaunchKernelGGL(pick_single(count, sh, a.has_pieces != 0u), dim3(GRT_TILE_GRID2), dim3(kWG), 0, stream, b);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("k_render_tile (one ray per wave) launch: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+#else
 static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode, bool pieces)
 {
 #define GRT_PICK3(C, S, P)                                                                                 \
-    (mode == 2 ? k_render_tile<C, S, true, 2, P> : (mode == 1 ? k_render_tile<C, S, true, 1, P>            \
-               : (mesh ? k_render_tile<C, S, true, 0, P> : k_render_tile<C, S, false, 0, P>)))
+    (mode == 1 ? k_render_tile<C, S, true, 1, P> : (mesh ? k_render_tile<C, S, true, 0, P> : k_render_tile<C, S, false, 0, P>))
 #define GRT_PICK2(C, S) (pieces ? GRT_PICK3(C, S, true) : GRT_PICK3(C, S, false))
     return count ? (sh ? GRT_PICK2(true, true) : GRT_PICK2(true, false)) : (sh ? GRT_PICK2(false, true) : GRT_PICK2(false, false));
 #undef GRT_PICK2
@@ -1269,7 +1298,7 @@ static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode, bool piece
 
 // mode 0: camera rays (mesh = stage 2 of the wavefront pipeline: up to their mesh hit); mode 1: stage 3, one wave per
 // chunk of a.queue_in (grid = the most chunks there can be: one per 8x8 tile of the launch); mode 2: one wave per ray of
-// the heavy list, a resident grid striding over it
+// the heavy list, a resident grid drawing from it (grt_render_tile_single.hip)
 int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err)
 {
     if (a.n_blocks == 0) return GRT_OK;
@@ -1282,11 +1311,11 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
         if (err) *err = "tile kernel: continuation queues missing";
         return GRT_ERR_INVALID;
     }
+    if (mode == 2) return launch_render_tile_single(a, count, stream, err);
     const bool sh = a.p.sh_degree_max > 0;
     RenderArgs b = a;
     b.heavy_role = 0;
-    const uint32_t grid = (mode == 2) ? 2048u : a.n_blocks * 4u; // mode 2: 8 waves per CU are resident (19 KB of LDS each)
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, stream, b);
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(a.n_blocks * 4u), dim3(kWG), 0, stream, b);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("k_render_tile launch: ") + hipGetErrorString(e);
@@ -1294,5 +1323,6 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
     }
     return GRT_OK;
 }
+#endif
 
 } // namespace grt

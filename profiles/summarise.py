@@ -5,12 +5,23 @@ bench.py runs first is skipped: only dispatches after the first 2 are used)."""
 import csv, datetime, glob, json, os, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
+wl = sys.argv[3] if len(sys.argv) > 3 else "C3"
 here = os.path.dirname(os.path.abspath(__file__))
-KERNEL = "k_render_tile<false, false, false, 0>"
+if wl != "C3":
+    tag = f"{tag}_{wl}"
+bench_line = None
+for line in open(src + "/bench_under_rocprof.log"):
+    if line.startswith("{"):
+        bench_line = json.loads(line)
+# the dominant kernel is the one the bench line names (tile kernel: <COUNT, SH, MESH, MODE, PIECES>)
+KERNEL = bench_line["roofline"]["kernel"].replace("grt::", "") if bench_line else "k_render_tile<false, false, false, 0, false>"
+# mesh frames: the stages of the wavefront pipeline are kernels of their own
+STAGES = ["k_primary_mesh<false>", "k_render_tile<false, false, true, 0,", "k_queue_mesh<false>", "k_render_tile<false, false, true, 1,",
+          "k_render_tile<false, false, true, 2,", "k_bounce<false>"] if "true, 0" in KERNEL else []
 
 for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if "rocprim" not in r[0] and float(r[4]) >= 0.05][:14]
+    keep = [rows[0]] + [r for r in rows[1:] if "rocprim" not in r[0] and float(r[4]) >= 0.05][:16]
     with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w", newline="") as o:
         csv.writer(o).writerows(keep)
 for line in open(src + "/bench_under_rocprof.log"):
@@ -31,8 +42,15 @@ def per_kernel(pattern, name_filter, skip):
     return out
 
 out = per_kernel(src + "/pmc*/**/*counter_collection.csv", lambda n, r: KERNEL in n, 2)
-res = {"kernel": "grt::" + KERNEL, "workload": "C3 (bench.py default), steady-state frames", "collected": datetime.date.today().isoformat(),
+res = {"kernel": "grt::" + KERNEL, "workload": f"{wl} (bench.py --workload {wl}), steady-state frames", "collected": datetime.date.today().isoformat(),
        "per_dispatch": out}
+if STAGES:  # SQ counters of every stage of the wavefront pipeline (per dispatch, averaged over the steady-state frames)
+    res["stages"] = {}
+    for st in STAGES:
+        o = per_kernel(src + "/pmc*/**/*counter_collection.csv", lambda n, r, st=st: st in n, 3)
+        if o.get("SQ_WAVES"):
+            w_ = o["SQ_WAVES"]
+            res["stages"][st] = {"waves_per_dispatch": round(w_, 1), "per_wave": {k: round(v / w_, 1) for k, v in o.items() if k.startswith("SQ_")}}
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     res["hbm_bytes_per_launch"] = int((2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024)  # MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE x2
     res["hbm_bytes_per_launch_raw"] = int((out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024)
@@ -52,6 +70,11 @@ if "SQ_WAVES" in out and "SQ_INSTS_VALU" in out:
     # independent ones; this kernel's waves issue one every `cycles_per_valu_inst_per_simd` (SQ_WAVE_CYCLES counts
     # quad-cycles of ONE wave; 4 waves share the SIMD).
     cyc = 4.0 * out["SQ_WAVE_CYCLES"] / out["SQ_INSTS_VALU"] / 4.0
+    if "SQ_WAIT_ANY" in out and "SQ_ACTIVE_INST_ANY" in out and "SQ_WAIT_INST_ANY" in out:
+        wc = out["SQ_WAVE_CYCLES"]
+        res["wave_time_split"] = {"issuing": round(out["SQ_ACTIVE_INST_ANY"] / wc, 3), "issue_stalled": round(out["SQ_WAIT_INST_ANY"] / wc, 3),
+                                  "waiting_on_waitcnt": round(out["SQ_WAIT_ANY"] / wc, 3),
+                                  "note": "fractions of SQ_WAVE_CYCLES (the three are disjoint, MI355X_MICROARCH.md)"}
     v = {"valu_insts_per_wave": round(out["SQ_INSTS_VALU"] / w), "salu_insts_per_wave": round(out["SQ_INSTS_SALU"] / w),
          "waves_per_simd": 4,
          "cycles_per_valu_inst_per_simd": round(cyc, 2),
@@ -76,7 +99,7 @@ if "SQ_WAVES" in out and "SQ_INSTS_VALU" in out:
 json.dump(res, open(os.path.join(here, f"{tag}_counters.json"), "w"), indent=1)
 tpath = os.path.join(here, "traffic.json")
 tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-tj["C3_sh0_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
+tj[f"{wl}_sh0_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
                       "kernel": res["kernel"], "source": f"profiles/{tag}_counters.json"}
 json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(res, indent=1))
