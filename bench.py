@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (cold frame, orbit, the other pipelining depth)")
     ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
     ap.add_argument("--split", type=int, default=-1, help="GRT_OPT_SPLIT (piece length of the spatial splits, quarters of the typical proxy diagonal; 0 = off; -1 = library default)")
+    ap.add_argument("--band-abs", type=int, default=-1, help="GRT_OPT_TILE_BAND_ABS (-1 = library default)")
     ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one process, one GPU: do the work of ONE rank of an N-rank run (tile list, frame slots, "
@@ -233,6 +234,8 @@ def main():
         else:
             t = trs[0].view()
         t.set_option(grt.OPT_KERNEL, args.kernel)
+        if args.band_abs >= 0:
+            t.set_option(grt.OPT_TILE_BAND_ABS, args.band_abs)
         trs.append(t)
     tr = trs[0]
     setup_s = (time.time() - t0) / n_ctx

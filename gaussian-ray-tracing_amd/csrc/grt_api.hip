@@ -574,6 +574,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
+    else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
     else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; }
     else if (option == GRT_OPT_OVF_ENTRIES) {
         if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
@@ -691,7 +692,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         if (rc == GRT_OK) {
             double sum = 0.0; uint64_t cnt = 0;
             for (int b = 0; b < grid; b++) { sum += h_part[b]; cnt += h_pcnt[b]; }
-            if (cnt) tau = (float)(0.25 * c->opt_split * std::exp(sum / (double)cnt));
+            if (cnt) { c->gm_diag = (float)std::exp(sum / (double)cnt); tau = 0.25f * (float)c->opt_split * c->gm_diag; }
         }
         if (rc == GRT_OK && tau > 0.0f) {
             hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau, d_cnt);
@@ -1235,6 +1236,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.tile_band = (float)c->opt_tile_band / 1024.0f;
     a.tile_look = (float)c->opt_tile_look / 1024.0f;
     a.tile_reserve = (uint32_t)c->opt_tile_reserve;
+    a.tile_band_abs = (float)c->opt_band_abs / 64.0f * sc->gm_diag;
     a.tile_prio_div = (uint32_t)c->opt_tile_prio;
     if (tile_kernel) {
         if (!c->ovf_zeroed) CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));

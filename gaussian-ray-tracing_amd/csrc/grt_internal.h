@@ -107,6 +107,7 @@ struct RenderArgs {
     uint32_t tile_ready_min; // lanes that must hold a final event before a compositing sweep starts
     float tile_band;         // particles within F * (1 + band) of the front are tested in one batch
     float tile_look;         // nodes within Fn * (1 + look) are expanded in one step
+    float tile_band_abs;     // trees with pieces: absolute floor of band / look-ahead (world units: a multiple of the typical proxy size)
     uint32_t tile_reserve;   // free frontier slots below which leaf steps are forced
     uint32_t tile_prio_div;  // the first 1/div of the cost-sorted launch order runs at raised wave priority (0 = off)
     float4* ovf_pool;        // window overflow bags: [chunk][entry][lane] x 16 B, one chunk per tile that overflows
@@ -213,6 +214,8 @@ struct grt_ctx {
     int opt_swizzle = 2;
     int opt_tile_ready = 16, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24, opt_tile_prio = 0; // band / look in 1/1024
     int opt_size_classes = 1;
+    int opt_band_abs = 512;       // GRT_OPT_TILE_BAND_ABS: that floor in 1/64 of the geometric-mean proxy diagonal
+    float gm_diag = 0.f;          // geometric mean of the proxies' box diagonals (grt_build_bvh)
     int opt_split = 8;            // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off)
     uint32_t n_hittable = 0;      // particles with opacity > alpha_min (BVH primitives = these, or their pieces)
     float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags

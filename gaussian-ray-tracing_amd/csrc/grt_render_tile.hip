@@ -848,7 +848,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
-                    const float hz = F + F * look_;
+                    const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs) : F * look_);
                     const bool node_near = wave_any(occ_l && !rng_l && (fl <= hz));
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
@@ -856,7 +856,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     float Fr = Ff_cur, Fn = Ff_cur;
                     if (leaf_step && !wave_any(rng_l && (fl <= Ff_cur))) Fr = wave_min(rng_l ? fl : INFINITY);
                     if (!leaf_step && !node_near) Fn = wave_min(rng_l ? INFINITY : fl);
-                    const float tau = leaf_step ? (Fr + Fr * band_) : fmaxf(hz, Fn);
+                    // (a tree with pieces holds sheets and needles that reach up to the eye: near the eye a band RELATIVE to the
+                    //  front is a sliver and a leaf step would take one range at a time — there the band has an absolute floor)
+                    const float tau = leaf_step ? (Fr + (PIECES ? fmaxf(Fr * band_, a.tile_band_abs) : Fr * band_)) : fmaxf(hz, Fn);
                     const bool cand = occ_l && (rng_l == leaf_step);
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
                     // one node: a frontier full of internal nodes overflows to the depth-first stack)

@@ -172,6 +172,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          sheet that is not axis-aligned) enters the LBVH as up to 512 pieces, each with the box of its cell;
                                          value = piece length in quarters of the geometric-mean proxy diagonal (default 8 = 2 x; 0 = off).
                                          Pure acceleration structure: same hits, same pixels.  Per context; next build */,
+       GRT_OPT_TILE_BAND_ABS = 25     /* trees with pieces: absolute floor of the tile kernel's leaf band and node look-ahead, in 1/64 of the
+                                         geometric-mean proxy diagonal (default 512 = 8 x; 0 = relative bands only).  Scheduling only */,
        /* testing knobs (frames never change; speed and the failure signal do) */
        GRT_OPT_OVF_CHUNKS = 21        /* tile kernel's pool of window-overflow bags: 0 (default) = sized from the demand of the
                                          frames before; n > 0: exactly n chunks; < 0: no pool (every overflow costs another pass) */,

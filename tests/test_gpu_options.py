@@ -44,6 +44,21 @@ def test_options_do_not_change_pixels():
                 assert (a8 == ref8).all() and (af == reff).all(), (opt, v)
         tr.set_option(opt, {grt.OPT_TILE_READY_MIN: 16, grt.OPT_TILE_BAND: 64, grt.OPT_TILE_LOOKAHEAD: 64,
                             grt.OPT_TILE_RESERVE: 24, grt.OPT_TILE_PRIO_DIV: 0}[opt])
+    # a tree with pieces (needles and sheets): the absolute band floor of its kernel is scheduling only
+    raw = grt.synth_scene(19, 20000)
+    raw["scale"] = (raw["scale"] + np.random.default_rng(3).normal(0.0, 1.6, size=raw["scale"].shape)).astype(np.float32)
+    acts2 = grt.activate(raw)
+    tr.upload(acts2)
+    assert tr.bvh_info()["n_primitives"] > tr.bvh_info()["n_proxies"]
+    p2 = grt.default_params(256, 160, grt.gaussian_center(acts2["pos"]))
+    b8, bf = tr.render(p2, want_f32=True)
+    b8, bf = b8.clone(), bf.clone()
+    for v in (0, 64, 100000):
+        tr.set_option(grt.OPT_TILE_BAND_ABS, v)
+        a8, af = tr.render(p2, want_f32=True)
+        assert (a8 == b8).all() and (af == bf).all(), v
+    tr.set_option(grt.OPT_TILE_BAND_ABS, 512)
+    tr.upload(acts)
     with pytest.raises(grt.GrtError):
         tr.set_option(grt.OPT_LEAF_MAX, 9)
     with pytest.raises(grt.GrtError):
