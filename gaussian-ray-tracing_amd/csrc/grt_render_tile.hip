@@ -760,7 +760,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         const uint64_t ek = k0;
                         const uint32_t cell = (uint32_t)(ek & kCellMask);
                         const uint32_t id = skey_id(ek);
-                        float ea = 0.0f, eo = INFINITY;
+                        float ea = 0.0f, eo = INFINITY, T_old = 0.0f;
+                        bool blend_ = false;
                         float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (can_) { // payload from LDS and (degree 0) the colour, both in flight while the window is popped
                             ea = PL_ALPHA(cell); eo = PL_OTHER(cell);
@@ -780,15 +781,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             if (COUNT) c.hit_evals++;
                             last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
                             if (a.p.alpha_min < ea) {
-                                f3 L;
-                                if (!SH) {
-                                    L = mk3(cc.x, cc.y, cc.z);
+                                if (!SH) { // degree 0: the colour load is still in flight; its use waits until the re-key is done
+                                    blend_ = true;
+                                    T_old = T;
                                 } else {
                                     f3 dl = dn; // keep the SH basis out of loop-invariant hoisting (it would spill)
                                     asm volatile("" : "+v"(dl.x), "+v"(dl.y), "+v"(dl.z));
-                                    L = sh_radiance(a.sh + (size_t)id * 48, dl, a.p.sh_degree_max);
+                                    const f3 L = sh_radiance(a.sh + (size_t)id * 48, dl, a.p.sh_degree_max);
+                                    radiance = add3(radiance, mul3s(mul3s(L, T), ea));
                                 }
-                                radiance = add3(radiance, mul3s(mul3s(L, T), ea));
                                 T *= (1.0f - ea);
                             }
                             if (!(T > minT)) alive = false;
@@ -802,6 +803,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             if (rekey) PL_OTHER(cell) = INFINITY;
                             SLOT_INSERT(nk) // a slot was just freed: it fits
                         }
+                        // (same value, (L T) alpha per channel with the T of before the event; placed here so that the gather of
+                        //  color0 has the window pop and the re-key to hide behind)
+                        if (!SH && blend_) radiance = add3(radiance, mul3s(mul3s(mk3(cc.x, cc.y, cc.z), T_old), ea));
                     }
                 }
                 if (done) break;
