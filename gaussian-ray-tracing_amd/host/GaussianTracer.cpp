@@ -29,7 +29,7 @@ GaussianTracer::~GaussianTracer()
 
 void GaussianTracer::initializeOptix() // src/GaussianTracer.cpp:72-83
 {
-    hipglue::setDevice(m_device);
+    // (grt_create makes m_device this thread's current device: the stream of initializeParams is created on it)
     if (grt_create(&m_ctx, m_device) != GRT_OK) throw std::runtime_error(grt_last_error(nullptr));
     createGaussianParticlesBVH();
     initializeParams();
