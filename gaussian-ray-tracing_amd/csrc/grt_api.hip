@@ -6,7 +6,6 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <cstring>
 #include <string>
@@ -676,7 +675,6 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         const int grid = (int)std::min<uint32_t>((n + 255) / 256, 256u);
         std::vector<float> h_part(grid);
         std::vector<uint32_t> h_pcnt(grid);
-        size_t tmp_bytes = 0;
         if ((e = hipMalloc(&d_part, grid * sizeof(float))) != hipSuccess || (e = hipMalloc(&d_pcnt, grid * sizeof(uint32_t))) != hipSuccess ||
             (e = hipMalloc(&d_cnt, (size_t)n * sizeof(uint32_t))) != hipSuccess || (e = hipMalloc(&d_offs, (size_t)n * sizeof(uint32_t))) != hipSuccess) {
             c->err = std::string("grt_build_bvh: hipMalloc(split): ") + hipGetErrorString(e);
@@ -696,9 +694,8 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         }
         if (rc == GRT_OK && tau > 0.0f) {
             hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau, d_cnt);
-            e = rocprim::exclusive_scan(nullptr, tmp_bytes, d_cnt, d_offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream);
-            if (e == hipSuccess) e = hipMalloc(&d_scan_tmp, tmp_bytes ? tmp_bytes : 16);
-            if (e == hipSuccess) e = rocprim::exclusive_scan(d_scan_tmp, tmp_bytes, d_cnt, d_offs, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream);
+            if (device_exclusive_scan_u32(d_cnt, d_offs, n, c->stream, &c->err) != GRT_OK) rc = GRT_ERR_HIP;
+            e = hipSuccess;
             uint32_t last_off = 0, last_cnt = 0;
             if (e == hipSuccess) e = hipMemcpyAsync(&last_off, d_offs + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(&last_cnt, d_cnt + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);

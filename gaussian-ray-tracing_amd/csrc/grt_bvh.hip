@@ -5,7 +5,7 @@
 // Pipeline (all on the device, one stream):
 //   1. k_scene_bounds   centroid bounds + count of valid primitives (wave reduce -> ordered-int atomics)
 //   2. k_morton         63-bit Morton key of the box centroid (21 bits / axis); invalid => ~0 (sorts last)
-//   3. rocprim radix sort of (key, primitive index)
+//   3. stable LSD radix sort of (key, primitive index), hand-written (radix_sort_pairs_64_32 below)
 //   4. k_leaf_boxes     boxes gathered into sorted order
 //   5. k_hierarchy      Karras 2012 internal nodes from the sorted keys (ties broken by index)
 //   6. k_refit_pass     bottom-up boxes, one launch per tree level: a node is finished in pass p only
@@ -20,7 +20,6 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "grt_internal.h"
 
@@ -170,6 +169,180 @@ __global__ void k_leaf_boxes(const float4* __restrict__ lo, const float4* __rest
     const uint32_t i = order[j];
     lb_lo[j] = lo[i];
     lb_hi[j] = hi[i];
+}
+
+// ---- hand-written stable LSD radix sort of (64-bit Morton key, 32-bit primitive index) pairs -------------------------
+// Eight passes of 8 bits.  Per pass: k_rs_hist (one 256-bin histogram per 2048-key tile, in LDS), k_rs_scan (ONE
+// workgroup: exclusive scan of the bin-major [256][tiles] table, i.e. every tile's first output slot per digit),
+// k_rs_scatter (the tile again, 256 keys at a time IN ORDER: a key's rank among the tile's equal digits = what earlier
+// rounds of the tile counted + what lower waves of this round counted + its rank inside the wave, from eight ballots —
+// gfx950 has no match-any — so the sort is stable and Karras' index tie-break keeps meaning the input order).
+// 24 launches, ~0.3 ms for 1 M keys; the build is one-off.  k_rs_check proves the result (sorted, stable) on the device
+// after every build: a wrong tree would otherwise only show as missing hits.
+constexpr uint32_t kRsTile = 2048u; // keys per workgroup and pass (8 rounds of 256)
+
+__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t n_tiles,
+                                                 uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kRsTile;
+    for (uint32_t r = 0; r < kRsTile / 256u; r++) {
+        const uint32_t i = base + r * 256u + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `cnt` uint32 values in place, one workgroup of 1024 (the table of a pass: 256 x tiles entries)
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ v, uint32_t cnt)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < cnt; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t x = i < cnt ? v[i] : 0u;
+        uint32_t incl = x;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= (uint32_t)off) incl += y;
+        }
+        if (lane == 63u) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wv; w++) before += wsum[w];
+        if (i < cnt) v[i] = before + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rs_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                    uint32_t shift, uint32_t n_tiles, const uint32_t* __restrict__ offs,
+                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t next[256];     // next free output slot of every digit for this tile
+    __shared__ uint32_t wcnt[4][256];  // keys of every digit in each wave of the current round
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    next[threadIdx.x] = offs[threadIdx.x * n_tiles + blockIdx.x];
+    const uint32_t base = blockIdx.x * kRsTile;
+    for (uint32_t r = 0; r < kRsTile / 256u; r++) {
+        for (uint32_t w = 0; w < 4u; w++) wcnt[w][threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t i = base + r * 256u + threadIdx.x;
+        const bool ok = i < n;
+        const uint64_t key = ok ? keys[i] : 0ull;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        // lanes of this wave that hold the same digit (and a key at all)
+        uint64_t same = __ballot(ok);
+        for (uint32_t b = 0; b < 8u; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (ok && rank == 0u) wcnt[wv][d] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (ok) {
+            uint32_t pos = next[d] + rank;
+            for (uint32_t w = 0; w < wv; w++) pos += wcnt[w][d];
+            keys_out[pos] = key;
+            vals_out[pos] = vals[i];
+        }
+        __syncthreads();
+        next[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// ---- exclusive scan of n uint32 values (the piece offsets of grt_build_bvh's spatial splits): per 1024-value block its
+// sum, one-workgroup scan of the block sums (k_rs_scan), then every block scans itself on top of its offset ----
+__global__ __launch_bounds__(1024) void k_scan_block_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ bsum)
+{
+    __shared__ uint32_t wsum[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t x = i < n ? in[i] : 0u;
+    for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+    if ((threadIdx.x & 63u) == 0u) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; w++) t += wsum[w];
+        bsum[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ boffs,
+                                                      uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t x = i < n ? in[i] : 0u;
+    uint32_t incl = x;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += y;
+    }
+    if (lane == 63u) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t before = boffs[blockIdx.x];
+    for (uint32_t w = 0; w < wv; w++) before += wsum[w];
+    if (i < n) out[i] = before + incl - x;
+}
+int device_exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint32_t n, hipStream_t stream, std::string* err)
+{
+    if (n == 0) return GRT_OK;
+    const uint32_t nb = (n + 1023u) / 1024u;
+    uint32_t* d_bsum = nullptr;
+    hipError_t e = hipMalloc(&d_bsum, sizeof(uint32_t) * nb);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(1024), 0, stream, d_in, n, d_bsum);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, d_bsum, nb);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, stream, d_in, n, d_bsum, d_out);
+        e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(d_bsum);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("device_exclusive_scan_u32: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+
+// sorted ascending, and stable (equal keys keep the order of their values = input positions): else *bad is set
+__global__ void k_rs_check(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t* __restrict__ bad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1u >= n) return;
+    const uint64_t a = keys[i], b = keys[i + 1u];
+    if (a > b || (a == b && vals[i] >= vals[i + 1u])) atomicOr(bad, 1u);
+}
+
+// keys / vals are clobbered (ping-pong); the sorted pairs end in keys_out / vals_out.  tmp: 256 x tiles uint32.
+static hipError_t radix_sort_pairs_64_32(uint64_t* keys, uint64_t* keys_out, uint32_t* vals, uint32_t* vals_out, uint32_t n,
+                                         uint32_t* tmp, hipStream_t stream)
+{
+    const uint32_t n_tiles = (n + kRsTile - 1u) / kRsTile;
+    uint64_t* k[2] = {keys, keys_out};
+    uint32_t* v[2] = {vals, vals_out};
+    int in = 0;
+    for (uint32_t pass = 0; pass < 8u; pass++) { // (an even number of passes: the result lands in keys_out after a final swap below)
+        hipLaunchKernelGGL(k_rs_hist, dim3(n_tiles), dim3(256), 0, stream, k[in], n, pass * 8u, n_tiles, tmp);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, tmp, 256u * n_tiles);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(n_tiles), dim3(256), 0, stream, k[in], v[in], n, pass * 8u, n_tiles, tmp, k[in ^ 1], v[in ^ 1]);
+        in ^= 1;
+    }
+    // eight passes: the sorted data is back in keys / vals — the caller wants it in keys_out / vals_out
+    hipError_t e = hipMemcpyAsync(keys_out, k[in], sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vals_out, v[in], sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    return e;
 }
 
 __device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int m, int i, int j)
@@ -593,13 +766,23 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
         hipLaunchKernelGGL(k_morton, dim3((n_in + B - 1) / B), dim3(B), 0, stream, d_lo, d_hi, n_in, d_bounds, d_keys,
                            d_vals, want_quad ? size_classes : 0);
     }
-    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
-                                     stream));
-    HIPCHK(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16));
-    HIPCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, out->order, (size_t)n_in, 0u, 64u,
-                                     stream));
-    HIPCHK(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    // (d_vals2: the sort ping-pongs between two pairs of arrays; out->order receives the sorted indices)
+    tmp_bytes = sizeof(uint32_t) * (256u * ((n_in + kRsTile - 1u) / kRsTile) + 1u);
+    HIPCHK(hipMalloc(&d_tmp, tmp_bytes));
+    {
+        uint32_t* d_bad = static_cast<uint32_t*>(d_tmp) + 256u * ((n_in + kRsTile - 1u) / kRsTile);
+        uint32_t h_bad = 0;
+        HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), stream));
+        HIPCHK(radix_sort_pairs_64_32(d_keys, d_keys2, d_vals, out->order, n_in, static_cast<uint32_t*>(d_tmp), stream));
+        hipLaunchKernelGGL(k_rs_check, dim3((n_in + B - 1) / B), dim3(B), 0, stream, d_keys2, out->order, n_in, d_bad);
+        HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_bounds, d_bounds, sizeof(h_bounds), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h_bad) {
+            if (err) *err = "build_lbvh: internal error: the Morton sort is not sorted / not stable";
+            goto fail_limit;
+        }
+    }
     m = h_bounds[6];
     out->n_prims = m;
     for (int k = 0; k < 3; k++) {

@@ -177,7 +177,6 @@ int ply_parse_header(std::ifstream& f, PlyHeader& h)
     return GRT_ERR_IO;
 }
 
-const char* kNames[59] = {nullptr};
 void init_names(std::vector<std::string>& names)
 {
     names = {"x", "y", "z", "f_dc_0", "f_dc_1", "f_dc_2"};
@@ -202,7 +201,6 @@ inline float prop_as_float(const unsigned char* p, const PlyProp& pr)
 
 int grt_host_ply_count(const char* path, uint64_t* n_out)
 {
-    (void)kNames;
     if (!path || !n_out) return GRT_ERR_INVALID;
     std::ifstream f(path, std::ios::binary);
     if (!f) { g_host_err = std::string("cannot open ") + path; return GRT_ERR_IO; }

@@ -60,6 +60,8 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
 // gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
 int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
 void free_bvh(DevBvh* b);
+// exclusive scan of n uint32 values on the device (hand-written, grt_bvh.hip); synchronises the stream
+int device_exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint32_t n, hipStream_t stream, std::string* err);
 
 // Everything the render kernel reads, passed by value.
 struct RenderArgs {
