@@ -49,7 +49,10 @@ namespace {
 constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of RenderArgs::n_blocks)
 constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kernel
 constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
-constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
+#ifndef GRT_TILE_BAG
+#define GRT_TILE_BAG 256u
+#endif
+constexpr uint32_t kBag = GRT_TILE_BAG;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
 constexpr uint32_t kStack = kTileStack; // depth-first overflow stack (only when the LDS bag is full too; guarded; the launcher
                                   // admits only trees it can hold: tile_stack_fits).  LDS per wave must stay <= 10 KB:
                                   // 10304 B gave 15 waves per CU instead of 16 and cost 4 %
@@ -274,6 +277,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     __shared__ float pl_other[KS * kWG], pl_alpha[KS * kWG];
     __shared__ float pl_col[SINGLE ? 3 * KS * kWG : 1]; // MODE 2: the event's radiance, fetched by the lane that inserted it
     (void)pl_col;
+#ifdef GRT_TILE_ACC_LDS
+    __shared__ float4 acc_lds[SINGLE ? 1 : kWG]; // EXPERIMENT: (radiance, T) of every lane live here between compositing steps
+#endif
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
@@ -390,6 +396,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     const float minT = a.p.minTransmittance;
     float T = 1.0f - density_in; // the payload's density carries over from segment to segment (shaders/tracer.cuh:331)
     f3 radiance = mk3(0.0f, 0.0f, 0.0f);
+#ifdef GRT_TILE_ACC_LDS
+    if (!SINGLE) acc_lds[lane] = make_float4(0.0f, 0.0f, 0.0f, T);
+#endif
     if (COUNT && have_ray && tally) c.segments++;
     const uint64_t raym = wave_ballot(have_ray);
     if (a.root_ref != kNoRoot && raym) {
@@ -757,6 +766,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             continue;
                         }
                         GRT_D(hit_evals, 1)
+#ifdef GRT_TILE_ACC_LDS
+                        const float4 ac_ = acc_lds[lane];
+                        float T = ac_.w;
+                        f3 radiance = mk3(ac_.x, ac_.y, ac_.z);
+#endif
                         const uint64_t ek = k0;
                         const uint32_t cell = (uint32_t)(ek & kCellMask);
                         const uint32_t id = skey_id(ek);
@@ -806,6 +820,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         // (same value, (L T) alpha per channel with the T of before the event; placed here so that the gather of
                         //  color0 has the window pop and the re-key to hide behind)
                         if (!SH && blend_) radiance = add3(radiance, mul3s(mul3s(mk3(cc.x, cc.y, cc.z), T_old), ea));
+#ifdef GRT_TILE_ACC_LDS
+                        acc_lds[lane] = make_float4(radiance.x, radiance.y, radiance.z, T);
+#endif
                     }
                 }
                 if (done) break;
@@ -1133,6 +1150,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
         if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[unit], iters);
+#ifdef GRT_TILE_ACC_LDS
+        if (!SINGLE) { const float4 ac_ = acc_lds[lane]; T = ac_.w; radiance = mk3(ac_.x, ac_.y, ac_.z); }
+#endif
     }
     if (MODE == 1 && aborted) { // wave-uniform: nothing is written, the chunk's rays join the heavy list
         const uint64_t vm = wave_ballot(in_frame);
