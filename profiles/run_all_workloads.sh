@@ -1,5 +1,8 @@
 #!/bin/bash
 # Runs bench.py on every workload (one GPU) and on the emulated multi-GPU rank layouts; writes profiles/<tag>_bench*.json
+# (through gpurun only gpurun_out/ comes back from the GPU box: the raw lines are in gpurun_out/all_<tag>/*.json and the
+#  python block at the end can be re-run on them locally; profiles/collect.sh likewise: re-run profiles/summarise.py on
+#  gpurun_out/collect_<tag>[_<workload>])
 TAG=${1:-rXX}
 O=gpurun_out/all_$TAG
 mkdir -p $O
