@@ -24,7 +24,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, W, H, slots, out_path):
+def _worker(rank, world, port, W, H, slots, out_path, force=False):
     import bench
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,7 +41,8 @@ def _worker(rank, world, port, W, H, slots, out_path):
             u8, _, _ = sc.render(op, window=(x0, y0, x1, y1), threads=1, want_f32=False)
             out[j, : y1 - y0, : x1 - x0] = torch.from_numpy(u8[y0:y1, x0:x1])
 
-    loop = bench.FrameLoop(torch, tiles, W, H, world, rank, slots, "cpu", render_full=None, render_tiles=render_tiles, dist=dist)
+    loop = bench.FrameLoop(torch, tiles, W, H, world, rank, slots, "cpu", render_full=None, render_tiles=render_tiles, dist=dist,
+                           force_collective=force)
     for i in range(slots + 1):  # every slot, and slot 0 twice
         loop.step(i)
     if rank == 0:
@@ -62,6 +63,19 @@ def test_bench_frame_loop_over_gloo_equals_single_rank(world, tmp_path):
     for k in range(slots):
         assert (got[k] == ref).all(), k
     assert cnt["hit_evals"] > W * H
+
+
+def test_forced_collective_at_world_size_one_over_gloo(tmp_path):
+    """bench.py --force-collective: ONE rank still goes through tile list -> gather -> un-permute (the branch the GPU test
+    runs over RCCL in a child process); here over gloo."""
+    W, H, slots = 112, 80, 2
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker, args=(1, _free_port(), W, H, slots, out, True), nprocs=1, join=True)
+    acts, p, sc, op, _ = make_scene(31, 800, W, H, scale_boost=1.0)
+    ref, _, _ = sc.render(op, want_f32=False)
+    got = np.load(out)
+    for k in range(slots):
+        assert (got[k] == ref).all(), k
 
 
 def test_tile_bookkeeping():
