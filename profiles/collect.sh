@@ -14,13 +14,17 @@ set -e
 TAG=${1:-rXX}
 WL=${2:-C3}
 QUICK=${3:-}
+LABEL=${4:-}            # optional: suffix for a variant of the workload, the remaining arguments go to bench.py
+shift; shift; shift; shift || true   #   e.g. profiles/collect.sh r03 C3 "" sh3 --sh-degree 3
+BARGS="$@"
 R=$PWD
 export TMPDIR=/tmp
 SUF=""; [ "$WL" != "C3" ] && SUF="_$WL"
+[ -n "$LABEL" ] && SUF="${SUF}_$LABEL"
 O=$R/gpurun_out/collect_$TAG$SUF
 rm -rf $O; mkdir -p $O
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --workload $WL --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs $BARGS > $O/bench_under_rocprof.log 2>&1
 echo "trace done"
 i=0
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
@@ -29,13 +33,13 @@ PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
 for C in "${PASSES[@]}"; do
   i=$((i+1))
   if [ -n "$QUICK" ] && [ $i -le 3 ]; then continue; fi
-  rocprofv3 --pmc $C --output-format csv -d $O/pmc$i -o p -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/pmc$i.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc$i -o p -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs $BARGS > $O/pmc$i.log 2>&1
   echo "pass $i done: $C"
 done
-if [ "$WL" = "C3" ] && [ -z "$QUICK" ]; then
+if [ "$WL" = "C3" ] && [ -z "$QUICK" ] && [ -z "$LABEL" ]; then
   $R/profiles/calib/valu_calib > $O/valu_calib.json
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/calib_pmc -o p -- $R/profiles/calib/valu_calib > $O/calib_pmc.log 2>&1
   echo "calibration done"
 fi
 cd $R
-python3 profiles/summarise.py $O $TAG $WL
+python3 profiles/summarise.py $O $TAG $WL $LABEL

@@ -6,9 +6,12 @@ import csv, datetime, glob, json, os, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
 wl = sys.argv[3] if len(sys.argv) > 3 else "C3"
+label = sys.argv[4] if len(sys.argv) > 4 else ""
 here = os.path.dirname(os.path.abspath(__file__))
 if wl != "C3":
     tag = f"{tag}_{wl}"
+if label:
+    tag = f"{tag}_{label}"
 bench_line = None
 for line in open(src + "/bench_under_rocprof.log"):
     if line.startswith("{"):
@@ -101,7 +104,8 @@ if "SQ_WAVES" in out and "SQ_INSTS_VALU" in out:
 json.dump(res, open(os.path.join(here, f"{tag}_counters.json"), "w"), indent=1)
 tpath = os.path.join(here, "traffic.json")
 tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-tj[f"{wl}_sh0_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
+sh_deg = 3 if label == "sh3" else 0
+tj[f"{wl}_sh{sh_deg}_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
                       "kernel": res["kernel"], "source": f"profiles/{tag}_counters.json"}
 json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(res, indent=1))
