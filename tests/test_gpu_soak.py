@@ -43,3 +43,54 @@ def test_moving_camera_soak():
                     d = np.abs(f32[y0:y0 + 16, x0:x0 + 16].cpu().numpy() - rf32[y0:y0 + 16, x0:x0 + 16]).max()
                     assert d <= 1e-4, (i, x0, y0, d)
     tr.close(); tw.close(); sc.close()
+
+
+def test_moving_camera_soak_on_a_tree_with_pieces():
+    """The same kind of run on a needle / sheet scene (300 k Gaussians, per-axis log-scale noise 1.6), whose LBVH holds
+    pieces of split proxies: 60 cameras from outside to deep inside the cloud, pinhole / wide / fisheye, two frame slots
+    (a context and a view of it) alternating.  Every frame of the tile kernel (cell ownership + repeat rules) must equal
+    the round-based kernel's (per-event ownership only) bit for bit, with the same hit counters; no wave may give up; the
+    oracle on random windows."""
+    W, H = 960, 540
+    raw = grt.synth_scene(9, 300_000)
+    raw["scale"] = (raw["scale"] + np.random.default_rng(11).normal(0.0, 1.6, size=raw["scale"].shape)).astype(np.float32)
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    from common import acts_to_particles
+    import oracle as O
+    sc = O.Scene(acts_to_particles(acts))
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    info = tr.bvh_info()
+    assert info["n_primitives"] > 1.2 * info["n_proxies"]
+    slots = [tr, tr.view()]
+    tw = grt.Tracer(0)
+    tw.set_option(grt.OPT_KERNEL, 2)
+    tw.upload(acts)
+    rng = np.random.default_rng(13)
+    n = 60
+    for i in range(n):
+        ang = 2 * np.pi * i / n
+        r = 3.0 - 2.8 * abs(np.sin(2 * ang))  # from outside (3.0) to deep inside the cloud (0.2)
+        eye = np.float32([r * np.sin(ang), 0.5 * np.sin(3 * ang), r * np.cos(ang)])
+        fisheye = i % 13 == 0
+        p = grt.default_params(W, H, center, eye=eye, fovy=60.0 if i % 9 else 100.0, fisheye=fisheye)
+        t = slots[i % 2]
+        t.set_option(grt.OPT_COUNTERS, 1)
+        u8, f32 = t.render(p, want_f32=True)
+        c = t.counters()  # (raises when a wave gave up: the sticky error word)
+        t.set_option(grt.OPT_COUNTERS, 0)
+        assert c["stall_exits"] == 0, i
+        if i % 4 == 0:
+            tw.set_option(grt.OPT_COUNTERS, 1)
+            a8, af = tw.render(p, want_f32=True)
+            cw = tw.counters()
+            assert (a8 == u8).all() and (af == f32).all(), i
+            assert cw["hit_evals"] == c["hit_evals"], i
+            if not fisheye:
+                for _ in range(2):
+                    x0 = int(rng.integers(0, W - 16)); y0 = int(rng.integers(0, H - 16))
+                    _, rf32, _ = sc.render(to_oracle_params(p), window=(x0, y0, x0 + 16, y0 + 16), threads=8)
+                    d = np.abs(f32[y0:y0 + 16, x0:x0 + 16].cpu().numpy() - rf32[y0:y0 + 16, x0:x0 + 16]).max()
+                    assert d <= 1e-4, (i, x0, y0, d)
+    slots[1].close(); tr.close(); tw.close(); sc.close()
