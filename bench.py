@@ -49,7 +49,8 @@ WORKLOADS = {
     "C4": (3, 1_000_000, 1920, 1080, False, True, 2, 0.0),
     "C5": (5, 3_000_000, 3840, 2160, True, False, 32, 0.0),
 }
-TILE = 32
+TILE = 32  # screen tiles dealt round-robin to the ranks (--tile: any multiple of 16; smaller tiles balance better, larger ones
+           # keep neighbouring 8x8 wave tiles — which share BVH nodes and records — on one GPU)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 TRAFFIC_FILE = os.path.join("profiles", "traffic.json")
 
@@ -159,6 +160,7 @@ def build_scene(grt, workload):
 
 
 def main():
+    global TILE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -169,6 +171,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (cold frame, orbit, the other pipelining depth)")
     ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
     ap.add_argument("--split", type=int, default=-1, help="GRT_OPT_SPLIT (piece length of the spatial splits, quarters of the typical proxy diagonal; 0 = off; -1 = library default)")
+    ap.add_argument("--tile", type=int, default=TILE, help="edge of the screen tiles dealt round-robin to the ranks (multiple of 16)")
     ap.add_argument("--band-abs", type=int, default=-1, help="GRT_OPT_TILE_BAND_ABS (-1 = library default)")
     ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
@@ -181,6 +184,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per rank for `value` (0 = auto: 1 on one GPU, 4 on 2-4 GPUs, 8 on 8+)")
     args = ap.parse_args()
+    if args.tile <= 0 or args.tile % 16:
+        print("bench.py: --tile must be a positive multiple of 16", file=sys.stderr)
+        sys.exit(2)
+    TILE = args.tile
 
     import torch
     import grt
