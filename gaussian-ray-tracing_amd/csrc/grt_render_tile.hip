@@ -120,6 +120,20 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #ifndef GRT_TILE_CHECK_LANE
 #define GRT_TILE_CHECK_LANE 0u
 #endif
+#ifdef GRT_TILE_PROBE
+#ifndef GRT_PROBE_VDEP
+#define GRT_PROBE_VDEP 0
+#endif
+#ifndef GRT_PROBE_VIND
+#define GRT_PROBE_VIND 0
+#endif
+#ifndef GRT_PROBE_SALU
+#define GRT_PROBE_SALU 0
+#endif
+#ifndef GRT_PROBE_TRIP
+#define GRT_PROBE_TRIP 0
+#endif
+#endif
 #ifdef GRT_TILE_DIAG
 #define GRT_D(f, n) if (COUNT) w.f += (n);
 #elif defined(GRT_MARKS)
@@ -705,8 +719,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 if (!SINGLE && !dfs) {
                     bool sweep = done;
                     while (true) {
-                        const bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
-                        const uint64_t cm_ = wave_ballot(can_);
+                        bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
+                        uint64_t cm_ = wave_ballot(can_);
                         // a lane whose next final event sits in its bag needs a refill before it can go on
                         const bool need = bags && alive && (nb != 0u) && !can_ && (key_t(bagmin) < F) && (bagmin < lost) &&
                                           ((k0 == kKeyInvalid) || (k0 >= bagmin));
@@ -763,8 +777,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                 nb = w_;
                                 bagmin = newmin;
                             }
-                            continue;
+                            // (the refill and the compositing step are two if-thens in a row, not the arms of an if / else:
+                            //  the arms of a structurised if / else keep BOTH versions of the window alive, 27 register copies
+                            //  per compositing step)
+                            can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
+                            cm_ = wave_ballot(can_);
                         }
+                        if (!cm_) continue;
                         GRT_D(hit_evals, 1)
 #ifdef GRT_TILE_ACC_LDS
                         const float4 ac_ = acc_lds[lane];
@@ -974,6 +993,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         trip = false;
                         float4 r0, r1, r2, r3, e0, e1, e2, e3;
                         bool act_; // lanes the exact test is meant for
+#ifdef GRT_TILE_PROBE
+                        uint32_t ridx_probe_ = 0u;
+#endif
                         if (SINGLE) { // every surviving lane fetches and tests ITS particle
                             act_ = want && alive;
                             r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -988,6 +1010,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             wm &= wm - 1ull;
                             const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
                             const uint32_t ridx = pidx * 4u;
+#ifdef GRT_TILE_PROBE
+                            ridx_probe_ = ridx;
+#endif
                             r0 = sload4(a.rec, ridx); r1 = sload4(a.rec, ridx + 1); r2 = sload4(a.rec, ridx + 2);
                             r3 = sload4(a.rec, ridx + 3);
                             if (!BUNDLE) {
@@ -1017,6 +1042,22 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
                         GRT_D(proxy_tests, 1)
+#ifdef GRT_TILE_PROBE // sensitivity probes (profiles/r03_sensitivity.json): extra work per exact test, results untouched
+                        {
+                            float pr0_ = d_g.x, pr1_ = d_g.y;
+                            uint32_t ps_ = ridx_probe_;
+#pragma unroll
+                            for (int q_ = 0; q_ < GRT_PROBE_VDEP; q_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pr0_));
+#pragma unroll
+                            for (int q_ = 0; q_ < GRT_PROBE_VIND; q_++)
+                                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pr0_), "+v"(pr1_));
+#pragma unroll
+                            for (int q_ = 0; q_ < GRT_PROBE_SALU; q_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps_));
+#pragma unroll
+                            for (int q_ = 0; q_ < GRT_PROBE_TRIP; q_++)
+                                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "+s"(ps_) : "s"(a.rec + (ps_ & 0xffffu)) : "memory");
+                        }
+#endif
                         float te, tx;
                         float pa[10]; // slab_project(o_g)
                         if (BUNDLE) {
