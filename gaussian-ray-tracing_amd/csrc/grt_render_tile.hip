@@ -810,6 +810,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         // equal keys meet in the window when a split particle was inserted through two of its pieces: the first is
                         // composited, the repeat only gives its cell back
                         const bool dup_ = PIECES && can_ && ((ek | kCellMask) == last_key);
+                        const uint64_t dupm_ = PIECES ? wave_ballot((ek | kCellMask) == last_key) : 0ull;
                         if (can_ && !dup_) { // shaders/tracer.cuh:352-367
                             if (COUNT) c.hit_evals++;
                             last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
@@ -832,7 +833,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         const bool rekey = can_ && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
                         const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
                         pmask = (can_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
-                        if (wave_any(rekey)) { // wave-uniform branch
+                        const uint64_t rkm_ = cm_ & ~dupm_ & wave_ballot((((uint32_t)ek) & 32u) == 0u) & wave_ballot(eo < t_hi);
+                        if (rkm_) { // wave-uniform branch
                             if (rekey) PL_OTHER(cell) = INFINITY;
                             SLOT_INSERT(nk) // a slot was just freed: it fits
                         }
@@ -881,20 +883,23 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     gv = g == 0u;
                 } else {
                     // (no reductions here: the frontier minimum Ff of the loop top and two votes decide the step)
-                    const bool have_rng = wave_any(rng_l);
+                    // (votes on compound conditions as ANDs of votes on single compares: the vote of an AND goes through a
+                    //  0 / 1 register and a second compare, two VALU operations each)
+                    const uint64_t occm_ = wave_ballot(occ_l), rngm_ = wave_ballot(rng_l);
+                    const bool have_rng = rngm_ != 0ull;
                     // a nearly full frontier takes leaf steps whatever lies in front (testing particles early is always
                     // legal; spilling children to the depth-first stack stalls the front)
-                    const uint32_t nocc = (uint32_t)__popcll(wave_ballot(occ_l));
+                    const uint32_t nocc = (uint32_t)__popcll(occm_);
                     const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
                     const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs) : F * look_);
-                    const bool node_near = wave_any(occ_l && !rng_l && (fl <= hz));
+                    const bool node_near = (occm_ & ~rngm_ & wave_ballot(fl <= hz)) != 0ull;
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
                     // reduction
                     float Fr = Ff_cur, Fn = Ff_cur;
-                    if (leaf_step && !wave_any(rng_l && (fl <= Ff_cur))) Fr = wave_min(rng_l ? fl : INFINITY);
+                    if (leaf_step && !(rngm_ & wave_ballot(fl <= Ff_cur))) Fr = wave_min(rng_l ? fl : INFINITY);
                     if (!leaf_step && !node_near) Fn = wave_min(rng_l ? INFINITY : fl);
                     // (a tree with pieces holds sheets and needles that reach up to the eye: near the eye a band RELATIVE to the
                     //  front is a sliver and a leaf step would take one range at a time — there the band has an absolute floor)
@@ -906,7 +911,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     g = leaf_step ? (lane >> 2) : (lane / kTileWide);
                     j = leaf_step ? (lane & 3u) : (lane % kTileWide);
                     float th = tau;
-                    uint64_t sm = wave_ballot(cand && (fl <= th));
+                    const uint64_t candm_ = leaf_step ? rngm_ : (occm_ & ~rngm_);
+                    uint64_t sm = candm_ & wave_ballot(fl <= th);
                     if ((uint32_t)__popcll(sm) > maxb) {
                         // more candidates than the step can take: the NEAREST ones go first (four bisection steps on
                         // the distance threshold; lane order only breaks what is left of the tie)
@@ -915,14 +921,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         if (SINGLE) hi_ = fminf(tau, uni(wave_fmax((cand && (fl <= tau)) ? fl : 0.0f)));
                         for (int it = 0; it < GRT_BISECT; it++) {
                             const float mid = 0.5f * (lo_ + hi_);
-                            const uint32_t n_ = (uint32_t)__popcll(wave_ballot(cand && (fl <= mid)));
+                            const uint32_t n_ = (uint32_t)__popcll(candm_ & wave_ballot(fl <= mid));
                             const bool few = n_ <= maxb;
                             lo_ = few ? mid : lo_;
                             hi_ = few ? hi_ : mid;
                             if (few && n_ * 2u >= maxb && it >= 3) break;
                         }
                         th = lo_;
-                        sm = wave_ballot(cand && (fl <= th));
+                        sm = candm_ & wave_ballot(fl <= th);
                     }
                     const bool selm = cand && (fl <= th);
                     const uint32_t rk = lanes_below(sm);
@@ -960,12 +966,18 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #define GRT_PSIDE(P, MP)                                                                                   \
                 (__builtin_fmaf(P##x, (P##x >= 0.0f) ? hx_ : lx_,                                          \
                  __builtin_fmaf(P##y, (P##y >= 0.0f) ? hy_ : ly_, P##z * ((P##z >= 0.0f) ? hz_ : lz_))) >= (BUNDLE ? epsM + (MP) : epsM))
-                const bool inside = GRT_PSIDE(pL, mL) && GRT_PSIDE(pR, mR) && GRT_PSIDE(pB, mB) && GRT_PSIDE(pT, mT);
+                // (all four, no short circuit: a plane test costs the wave the same for one lane as for 64, and the votes on the
+                //  single compares AND together for nothing)
+                const bool in0_ = GRT_PSIDE(pL, mL), in1_ = GRT_PSIDE(pR, mR), in2_ = GRT_PSIDE(pB, mB), in3_ = GRT_PSIDE(pT, mT);
+                const bool inside = in0_ & in1_ & in2_ & in3_;
+                const uint64_t insidem_ = wave_ballot(in0_) & wave_ballot(in1_) & wave_ballot(in2_) & wave_ballot(in3_);
 #undef GRT_PSIDE
                 // lower bound of t over the tile: Euclidean distance to the box, and the per-axis slab bound
                 const float ex_ = fmaxf(fmaxf(lx_, -hx_), 0.0f), ey_ = fmaxf(fmaxf(ly_, -hy_), 0.0f),
                             ez_ = fmaxf(fmaxf(lz_, -hz_), 0.0f);
-                float euc = sqrtf(__builtin_fmaf(ex_, ex_, __builtin_fmaf(ey_, ey_, ez_ * ez_)));
+                // (v_sqrt_f32, 1 ulp, instead of the correctly rounded sqrtf and its 15 instructions: a bound that is cut by 2e-6
+                //  below; a denormal argument gives 0, a smaller bound still)
+                float euc = __builtin_amdgcn_sqrtf(__builtin_fmaf(ex_, ex_, __builtin_fmaf(ey_, ey_, ez_ * ez_)));
                 float sx_, sy_, sz_;
                 if (BUNDLE) { // |d| t >= dist(o, box) >= dist(oc, box) - |o - oc|;  t >= (side - o.x) / d.x per axis
                     euc = fmaxf(euc - rmax, 0.0f) * idmax;
@@ -975,20 +987,23 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 }
                 float lam = fmaxf(fmaxf(euc, sx_), fmaxf(sy_, sz_)) * (1.0f - 2e-6f);
                 lam = fmaxf(lam, F); // never below the current front (keeps the frontier monotone)
-                bool want = valid && inside && (lam <= LIM);
+                bool want = valid & inside & (lam <= LIM);
+                uint64_t wm = wave_ballot(gv) & (leaf_step ? wave_ballot(j < leaf_count(nref)) : ~0ull) & wave_ballot(cref != kNoRoot) &
+                              insidem_ & wave_ballot(lam <= LIM);
                 if (LO > 0.0f) { // later passes: skip what ends before the restart point
                     const float fx_ = fmaxf(fabsf(lx_), fabsf(hx_)), fy_ = fmaxf(fabsf(ly_), fabsf(hy_)),
                                 fz_ = fmaxf(fabsf(lz_), fabsf(hz_));
                     float far = sqrtf(__builtin_fmaf(fx_, fx_, __builtin_fmaf(fy_, fy_, fz_ * fz_))) * (1.0f + 2e-6f);
                     if (BUNDLE) far = (far + rmax) * idmin;
                     want = want && (far >= LO);
+                    wm &= wave_ballot(far >= LO);
                 }
-                uint64_t wm = wave_ballot(want);
 
                 if (leaf_step) {
                     GRT_D(fetches, 1)
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
+                    const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
                     while (SINGLE ? trip : (wm != 0ull)) {
                         trip = false;
                         float4 r0, r1, r2, r3, e0, e1, e2, e3;
@@ -1036,7 +1051,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         {   // conservative sphere pre-test (proxy_sphere_maybe_pre) as lane masks
                             const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
                             const uint64_t m_ = (wave_ballot(cc_ <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_)) &
-                                                wave_ballot(act_);
+                                                (SINGLE ? wave_ballot(act_) : alivem_);
                             if (!m_) continue;
                         }
                         if (COUNT && act_) c.proxy_tests++;
