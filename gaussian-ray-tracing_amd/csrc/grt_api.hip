@@ -64,24 +64,34 @@ __global__ void k_proxy_boxes(const float* __restrict__ pos, const float* __rest
     mat3_cast(quat[i * 4], quat[i * 4 + 1], quat[i * 4 + 2], quat[i * 4 + 3], Rg);
     const float sx = scale[i * 3] * s, sy = scale[i * 3 + 1] * s, sz = scale[i * 3 + 2] * s;
     float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float r2 = 0.0f; // largest squared distance of a vertex from the centre
 #pragma unroll
     for (int v = 0; v < 12; v++) {
         const float lx = sx * V[v][0], ly = sy * V[v][1], lz = sz * V[v][2];
+        float q2 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const float w = (Rg[0 * 3 + r] * lx + Rg[1 * 3 + r] * ly) + Rg[2 * 3 + r] * lz + pos[i * 3 + r];
+            const float wl = (Rg[0 * 3 + r] * lx + Rg[1 * 3 + r] * ly) + Rg[2 * 3 + r] * lz;
+            const float w = wl + pos[i * 3 + r];
             l[r] = fminf(l[r], w);
             h[r] = fmaxf(h[r], w);
+            q2 += wl * wl;
         }
+        r2 = fmaxf(r2, q2);
     }
+    float emax = 0.0f;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const float e = 1e-5f * (1.0f + fmaxf(fabsf(l[r]), fabsf(h[r])));
         l[r] -= e;
         h[r] += e;
+        emax = fmaxf(emax, e);
     }
+    // hi.w: radius of a sphere about the BOX CENTRE that holds the proxy (the vertices come in +- pairs, so the box centre is
+    // the particle's position up to the rounding the box margin e covers many times over): what the tile kernel's leaf step
+    // culls with besides the box, which for a round proxy reaches 1.5 x as far along an oblique plane normal
     lo[i] = make_float4(l[0], l[1], l[2], 0.0f);
-    hi[i] = make_float4(h[0], h[1], h[2], 0.0f);
+    hi[i] = make_float4(h[0], h[1], h[2], sqrtf(r2) * (1.0f + 1e-5f) + 3.0f * emax);
 }
 
 // ---- spatial splits of large anisotropic proxies -------------------------------------------------------------------
@@ -193,7 +203,7 @@ __global__ void k_piece_boxes(const float* __restrict__ pos, const float* __rest
         if (!(bl[k] <= bh[k])) { bl[k] = L[k]; bh[k] = H[k]; } // (cannot happen: the cell meets the proxy's box)
     }
     plo[j] = make_float4(bl[0], bl[1], bl[2], 0.0f);
-    phi[j] = make_float4(bh[0], bh[1], bh[2], 0.0f);
+    phi[j] = make_float4(bh[0], bh[1], bh[2], INFINITY); // (a cell has no bounding sphere worth testing: see k_proxy_boxes)
 }
 
 // sum over the hittable proxies of log(box diagonal), per workgroup (fixed order; the host adds the partials in double):

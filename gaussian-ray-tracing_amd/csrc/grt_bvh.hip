@@ -632,7 +632,7 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
     for (int e = 0; e < W; e++) {
         if (e < ne) {
             q[2 * e] = make_float4(box[e][0], box[e][1], box[e][2], __uint_as_float(ref[e]));
-            q[2 * e + 1] = make_float4(box[e][3], box[e][4], box[e][5], 0.0f);
+            q[2 * e + 1] = make_float4(box[e][3], box[e][4], box[e][5], INFINITY); // (.w: bounding radius, none for a node)
         } else {
             q[2 * e] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(kNoRoot));
             q[2 * e + 1] = make_float4(-1.0f, -1.0f, -1.0f, 0.0f);

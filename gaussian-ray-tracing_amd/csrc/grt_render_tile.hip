@@ -466,6 +466,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             const float s_ = P##x * dx_ + P##y * dy_ + P##z * dz_ - 8e-6f * ((fabsf(dx_) + fabsf(dy_)) + fabsf(dz_)); \
             MP = uni(wave_fmin((M) ? s_ : INFINITY));                                                      \
         }
+#define GRT_PNORM(P, X, Y, Z)                                                                              \
+        {                                                                                                  \
+            const float x_ = (X), y_ = (Y), z_ = (Z);                                                      \
+            const float il_ = pk_ / sqrtf(__builtin_fmaf(x_, x_, __builtin_fmaf(y_, y_, z_ * z_)));       \
+            P##x = uni(x_ * il_); P##y = uni(y_ * il_); P##z = uni(z_ * il_);                              \
+        }
 #define GRT_FRUSTUM(M)                                                                                     \
         {                                                                                                  \
             const float da = dot3(d, ax);                                                                  \
@@ -477,10 +483,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             float tv0 = uni(wave_fmin((M) ? tv : INFINITY)), tv1 = uni(wave_fmax((M) ? tv : -INFINITY));   \
             tu0 -= 1e-4f * (1.0f + fabsf(tu0)); tu1 += 1e-4f * (1.0f + fabsf(tu1));                        \
             tv0 -= 1e-4f * (1.0f + fabsf(tv0)); tv1 += 1e-4f * (1.0f + fabsf(tv1));                        \
-            pLx = uni(pk_ * (uu.x - tu0 * ax.x)); pLy = uni(pk_ * (uu.y - tu0 * ax.y)); pLz = uni(pk_ * (uu.z - tu0 * ax.z)); \
-            pRx = uni(pk_ * (tu1 * ax.x - uu.x)); pRy = uni(pk_ * (tu1 * ax.y - uu.y)); pRz = uni(pk_ * (tu1 * ax.z - uu.z)); \
-            pBx = uni(pk_ * (vv.x - tv0 * ax.x)); pBy = uni(pk_ * (vv.y - tv0 * ax.y)); pBz = uni(pk_ * (vv.z - tv0 * ax.z)); \
-            pTx = uni(pk_ * (tv1 * ax.x - vv.x)); pTy = uni(pk_ * (tv1 * ax.y - vv.y)); pTz = uni(pk_ * (tv1 * ax.z - vv.z)); \
+            /* unit normals (the leaf step sets a bounding sphere's radius against them); pk_ = 0: no plane at all */ \
+            GRT_PNORM(pL, uu.x - tu0 * ax.x, uu.y - tu0 * ax.y, uu.z - tu0 * ax.z)                             \
+            GRT_PNORM(pR, tu1 * ax.x - uu.x, tu1 * ax.y - uu.y, tu1 * ax.z - uu.z)                             \
+            GRT_PNORM(pB, vv.x - tv0 * ax.x, vv.y - tv0 * ax.y, vv.z - tv0 * ax.z)                             \
+            GRT_PNORM(pT, tv1 * ax.x - vv.x, tv1 * ax.y - vv.y, tv1 * ax.z - vv.z)                             \
             GRT_AXIS(M, x, ivx, shx, ofx)                                                                  \
             GRT_AXIS(M, y, ivy, shy, ofy)                                                                  \
             GRT_AXIS(M, z, ivz, shz, ofz)                                                                  \
@@ -960,12 +967,20 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 // box relative to the eye
                 const float lx_ = b0.x - oc.x, ly_ = b0.y - oc.y, lz_ = b0.z - oc.z;
                 const float hx_ = b1.x - oc.x, hy_ = b1.y - oc.y, hz_ = b1.z - oc.z;
-                // four frustum planes, each at the box corner farthest along its normal (wave-uniform choice); the
-                // slack covers the rounding of the three products (|n| < 2): 1e-5 x the L1 size of the box about the eye
-                const float epsM = -1e-5f * (((fabsf(lx_) + fabsf(hx_)) + (fabsf(ly_) + fabsf(hy_))) + (fabsf(lz_) + fabsf(hz_)));
+                // four frustum planes (unit normals n), everything times two: 2 n.centre + min(|n|.extent, 2 radius) is twice the
+                // farthest reach of (box AND bounding sphere) along n.  hi.w = the radius of a sphere about the box centre that
+                // holds the primitive (a proxy's vertices: grt_api.hip k_proxy_boxes; +inf for child boxes and pieces): for a round
+                // proxy the box corner reaches up to sqrt 3 times further along an oblique normal than the proxy does, a third
+                // of the particles a leaf step used to fetch.  The slack covers the rounding of the sums and products:
+                // 2e-5 x the L1 size of the box about the eye
+                const float epsM = -2e-5f * (((fabsf(lx_) + fabsf(hx_)) + (fabsf(ly_) + fabsf(hy_))) + (fabsf(lz_) + fabsf(hz_)));
+                const float cx_ = lx_ + hx_, cy_ = ly_ + hy_, cz_ = lz_ + hz_;
+                const float gx_ = hx_ - lx_, gy_ = hy_ - ly_, gz_ = hz_ - lz_;
+                const float rs_ = b1.w + b1.w;
 #define GRT_PSIDE(P, MP)                                                                                   \
-                (__builtin_fmaf(P##x, (P##x >= 0.0f) ? hx_ : lx_,                                          \
-                 __builtin_fmaf(P##y, (P##y >= 0.0f) ? hy_ : ly_, P##z * ((P##z >= 0.0f) ? hz_ : lz_))) >= (BUNDLE ? epsM + (MP) : epsM))
+                ((__builtin_fmaf(P##x, cx_, __builtin_fmaf(P##y, cy_, P##z * cz_)) +                        \
+                  fminf(__builtin_fmaf(fabsf(P##x), gx_, __builtin_fmaf(fabsf(P##y), gy_, fabsf(P##z) * gz_)), rs_)) >= \
+                 (BUNDLE ? epsM + 2.0f * (MP) : epsM))
                 // (all four, no short circuit: a plane test costs the wave the same for one lane as for 64, and the votes on the
                 //  single compares AND together for nothing)
                 const bool in0_ = GRT_PSIDE(pL, mL), in1_ = GRT_PSIDE(pR, mR), in2_ = GRT_PSIDE(pB, mB), in3_ = GRT_PSIDE(pT, mT);
