@@ -119,7 +119,9 @@ __device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float
 #pragma unroll
     for (int i = 0; i < 10; i++) {
         const float h = (i >= 4 && i <= 7) ? s3 : s;
-        const float ap = (b[i] < 0.0f) ? -a[i] : a[i];
+        // a with the sign of b folded in: the sign BIT of b (so b = -0 counts as negative; its slab then sits at -+1e30 times
+        // something on either reading and bounds nothing), two VALU operations instead of a compare, a move and a select
+        const float ap = __uint_as_float(__float_as_uint(a[i]) ^ (__float_as_uint(b[i]) & 0x80000000u));
         const float bp = fmaxf(fabsf(b[i]), 1e-30f);
         const float cn = -(ap + h);
         const float cf = h - ap;

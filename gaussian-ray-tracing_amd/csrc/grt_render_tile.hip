@@ -133,6 +133,9 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #ifndef GRT_PROBE_TRIP
 #define GRT_PROBE_TRIP 0
 #endif
+#ifndef GRT_PROBE_NOP
+#define GRT_PROBE_NOP 0
+#endif
 #endif
 #ifdef GRT_TILE_DIAG
 #define GRT_D(f, n) if (COUNT) w.f += (n);
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         const bool rekey = can_ && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
                         const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
                         pmask = (can_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
-                        const uint64_t rkm_ = cm_ & ~dupm_ & wave_ballot((((uint32_t)ek) & 32u) == 0u) & wave_ballot(eo < t_hi);
+                        const uint64_t rkm_ = cm_ & ~dupm_ & vote_eq_u32(((uint32_t)ek) & 32u, 0u) & vote_lt_f32(eo, t_hi);
                         if (rkm_) { // wave-uniform branch
                             if (rekey) PL_OTHER(cell) = INFINITY;
                             SLOT_INSERT(nk) // a slot was just freed: it fits
@@ -880,14 +883,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const bool rng_l = occ_l && ((fr & kLeafBit) != 0u);
                 bool leaf_step;
                 uint32_t nref; // the entry this lane's group expands
-                bool gv;       // group valid
+                uint32_t ngrp; // groups in this step (wave-uniform): group g is valid when g < ngrp
                 uint32_t g, j; // group of this lane and its child slot in the group: 4 lanes per leaf range, kTileWide per node
                 if (cur != kNoRoot) { // depth-first mode: one entry
                     leaf_step = (cur & kLeafBit) != 0u;
                     g = leaf_step ? (lane >> 2) : (lane / kTileWide);
                     j = leaf_step ? (lane & 3u) : (lane % kTileWide);
                     nref = cur;
-                    gv = g == 0u;
+                    ngrp = 1u;
                 } else {
                     // (no reductions here: the frontier minimum Ff of the loop top and two votes decide the step)
                     // (votes on compound conditions as ANDs of votes on single compares: the vote of an AND goes through a
@@ -946,10 +949,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     fr = sel ? kNoRoot : fr;
                     wave_fence();
                     nref = xsel[g];
-                    gv = g < cnt;
+                    ngrp = cnt;
                 }
                 const uint32_t first = leaf_first(nref);
-                const bool cv = gv && (!leaf_step || (j < leaf_count(nref)));
+                // (one compare per condition, made where it is voted on: a condition that arrives from another block as a
+                //  bool is voted on through a 0 / 1 register and a second compare)
+                const uint32_t jmax_ = leaf_step ? leaf_count(nref) : kTileWide;
+                const bool gv = g < ngrp;
+                const bool cv = gv & (j < jmax_);
                 float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
                 if (cv) {
                     const float4* src = leaf_step ? (a.pbox + (size_t)(first + j) * 2) : (a.qnodes + (size_t)nref * (2u * kTileWide) + j * 2u);
@@ -1003,8 +1010,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 float lam = fmaxf(fmaxf(euc, sx_), fmaxf(sy_, sz_)) * (1.0f - 2e-6f);
                 lam = fmaxf(lam, F); // never below the current front (keeps the frontier monotone)
                 bool want = valid & inside & (lam <= LIM);
-                uint64_t wm = wave_ballot(gv) & (leaf_step ? wave_ballot(j < leaf_count(nref)) : ~0ull) & wave_ballot(cref != kNoRoot) &
-                              insidem_ & wave_ballot(lam <= LIM);
+                uint64_t wm = wave_ballot(g < ngrp) & wave_ballot(j < jmax_) & wave_ballot(cref != kNoRoot) & insidem_ & wave_ballot(lam <= LIM);
                 if (LO > 0.0f) { // later passes: skip what ends before the restart point
                     const float fx_ = fmaxf(fabsf(lx_), fabsf(hx_)), fy_ = fmaxf(fabsf(ly_), fabsf(hy_)),
                                 fz_ = fmaxf(fabsf(lz_), fabsf(hz_));
@@ -1083,6 +1089,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                 asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pr0_), "+v"(pr1_));
 #pragma unroll
                             for (int q_ = 0; q_ < GRT_PROBE_SALU; q_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps_));
+#pragma unroll
+                            for (int q_ = 0; q_ < GRT_PROBE_NOP; q_++) asm volatile("s_nop 1");
 #pragma unroll
                             for (int q_ = 0; q_ < GRT_PROBE_TRIP; q_++)
                                 asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "+s"(ps_) : "s"(a.rec + (ps_ & 0xffffu)) : "memory");

@@ -92,6 +92,25 @@ __device__ __forceinline__ uint64_t wave_ballot(bool p)
 #endif
 }
 __device__ __forceinline__ bool wave_any(bool p) { return wave_ballot(p) != 0ull; }
+// votes on ONE compare, as the lane mask the compare instruction writes (v_cmp -> SGPR pair): whatever else uses the
+// condition, and wherever it was computed, the vote costs one VALU operation (wave_ballot of a bool that arrives from
+// another block costs two on top of its compare)
+__device__ __forceinline__ uint64_t vote_eq_u32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_uicmp(a, b, 32); // ICMP_EQ
+#else
+    return a == b;
+#endif
+}
+__device__ __forceinline__ uint64_t vote_lt_f32(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fcmp(a, b, 4); // FCMP_OLT
+#else
+    return a < b;
+#endif
+}
 // max(v, +0) for a non-NaN float as one integer max (negative floats are negative ints)
 __device__ __forceinline__ float clamp0(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 

@@ -340,7 +340,10 @@ static inline int proxy_slabs(f3 o_g, f3 d_g, float s, float* t_entry, float* t_
     float nn = 0.0f, nd = 0.0f, fn = 0.0f, fd = 0.0f;
     for (int i = 0; i < 10; i++) {
         const float h = (i >= 4 && i <= 7) ? s3 : s;
-        const float ap = (b[i] < 0.0f) ? -a[i] : a[i];
+        /* a with the sign of b folded in, by the sign BIT of b (b = -0 reads as negative: that slab is parallel to the ray and
+         * its two planes land at -+1e30 x something on either reading, so it bounds nothing; what matters is that the GPU
+         * kernels do the very same thing, grt_device.h: proxy_slabs_pre) */
+        const float ap = signbit(b[i]) ? -a[i] : a[i];
         const float bp = fmaxf(fabsf(b[i]), 1e-30f);
         const float cn = -(ap + h); /* near = cn / bp */
         const float cf = h - ap;    /* far  = cf / bp */

@@ -14,15 +14,16 @@ for l in L[s:e]:
     m=re.match(r'; GRT_MARK (\w+)',t)
     if m:
         piece=m.group(1)+('2' if m.group(1) in cnt else ''); continue
-    if piece not in cnt: cnt[piece]=[0,0,0,0]; order.append(piece)
+    if piece not in cnt: cnt[piece]=[0,0,0,0,0]; order.append(piece)
     if not t or t.startswith(';') or t.startswith('.') or t.endswith(':'): continue
     op=t.split()[0]
     cnt[piece][0]+=1
     if op=='v_mov_b64_e32' and not t.endswith('-1'): cnt[piece][1]+=1
     if op.startswith('scratch_'): cnt[piece][2]+=1
     if op.startswith('v_') : cnt[piece][3]+=1
-for p in order: print(f"{p:14s} instr={cnt[p][0]:5d} valu={cnt[p][3]:5d} mov64_e32={cnt[p][1]:3d} scratch={cnt[p][2]:3d}")
-print('total', sum(c[0] for c in cnt.values()), 'mov64_e32', sum(c[1] for c in cnt.values()), 'scratch', sum(c[2] for c in cnt.values()))
+    if op=='s_nop': cnt[piece][4]+=1+int(t.split()[1])
+for p in order: print(f"{p:14s} instr={cnt[p][0]:5d} valu={cnt[p][3]:5d} mov64_e32={cnt[p][1]:3d} scratch={cnt[p][2]:3d} nop_waitstates={cnt[p][4]:3d}")
+print('total', sum(c[0] for c in cnt.values()), 'mov64_e32', sum(c[1] for c in cnt.values()), 'scratch', sum(c[2] for c in cnt.values()), 'nop_ws', sum(c[4] for c in cnt.values()))
 for l in L[e:e+80]:
     if 'vgpr_spill_count' in l or 'NumVgprs' in l or 'ScratchSize' in l or '.vgpr_count' in l: print(l.strip())
 PY
