@@ -1153,7 +1153,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         const uint32_t h = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
         const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
         int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks,
-                                   uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max));
+                                   uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims));
         if (rcf != GRT_OK) return rcf;
     }
     if (c->opt_counters) CHK(c, hipMemsetAsync(c->d_counters, 0, kNumCounters * sizeof(unsigned long long), s));
@@ -1187,7 +1187,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.queue_alt = c->d_queue + c->wf_cap * 4;
         a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
-    const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max);
+    const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max, sc->gbvh.n_prims);
     // allocations first (they may synchronise): eye records of this slot, overflow pool
     const uint32_t m = sc->gbvh.n_prims;
     const bool want_erec = a.mode != 2 && m && c->opt_kernel != 1 && c->opt_kernel != 2;

@@ -185,10 +185,12 @@ inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
     return variant != 1 && variant != 2 && mode != 2 && stack_depth <= 120u;
 }
 // the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
-inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max)
+// (n_prims < 2^26: the tile kernel addresses the 64-B records by a 32-bit byte offset, scalar loads with an SGPR offset)
+constexpr uint32_t kTileMaxPrims = 1u << 26;
+inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max, uint32_t n_prims)
 {
     return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4 &&
-           tile_stack_fits(stack_depth);
+           tile_stack_fits(stack_depth) && n_prims < kTileMaxPrims;
 }
 // per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)
 int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,

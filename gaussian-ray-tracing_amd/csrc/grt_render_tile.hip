@@ -1043,18 +1043,16 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             wm = 0ull;
                         } else {
                             const uint32_t b = (uint32_t)__builtin_ctzll(wm);
-                            wm &= wm - 1ull;
+                            wm = clear_bit64(wm, b);
                             const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
-                            const uint32_t ridx = pidx * 4u;
+                            // (a 32-bit BYTE offset: the two 64-B scalar loads take it as their SGPR offset, no 64-bit address
+                            //  arithmetic; the launcher sends scenes of 2^26 primitives and more elsewhere, kTileMaxPrims)
+                            const uint32_t roff = pidx << 6;
 #ifdef GRT_TILE_PROBE
-                            ridx_probe_ = ridx;
+                            ridx_probe_ = pidx * 4u;
 #endif
-                            r0 = sload4(a.rec, ridx); r1 = sload4(a.rec, ridx + 1); r2 = sload4(a.rec, ridx + 2);
-                            r3 = sload4(a.rec, ridx + 3);
-                            if (!BUNDLE) {
-                                e0 = sload4(a.erec, ridx); e1 = sload4(a.erec, ridx + 1); e2 = sload4(a.erec, ridx + 2);
-                                e3 = sload4(a.erec, ridx + 3);
-                            }
+                            sload64(a.rec, roff, r0, r1, r2, r3);
+                            if (!BUNDLE) sload64(a.erec, roff, e0, e1, e2, e3);
                             if (COUNT) c.fetches += BUNDLE ? 4 : 8; // wave-uniform: 64-B record (+ 64-B eye record), in 16-B units
                             act_ = alive;
                         }

@@ -33,6 +33,32 @@ __device__ __forceinline__ float4 sload4(const float4* base, uint32_t idx)
 #endif
 }
 
+// one 64-B record by ONE scalar load at base + a 32-bit byte offset (s_load_dwordx16 sdst, sbase, soffset)
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload64(const float4* base, uint32_t byte_off, float4& q0, float4& q1, float4& q2, float4& q3)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) char* cptr1;
+    typedef const __attribute__((address_space(4))) v16f* cptr16;
+    const v16f v = *(cptr16)((cptr1)(uintptr_t)base + byte_off);
+    q0 = make_float4(v.s0, v.s1, v.s2, v.s3); q1 = make_float4(v.s4, v.s5, v.s6, v.s7);
+    q2 = make_float4(v.s8, v.s9, v.sa, v.sb); q3 = make_float4(v.sc, v.sd, v.se, v.sf);
+#else
+    const float4* p = (const float4*)((const char*)base + byte_off);
+    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+#endif
+}
+// x with bit b cleared, b wave-uniform (s_bitset0_b64: one SALU operation instead of the three of x & (x - 1))
+__device__ __forceinline__ uint64_t clear_bit64(uint64_t x, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_bitset0_b64 %0, %1" : "+s"(x) : "s"(b));
+    return x;
+#else
+    return x & ~(1ull << b);
+#endif
+}
+
 // wave64 min of non-negative floats (or +inf) -> wave-uniform value.  Their bit patterns order like unsigned
 // integers, so the reduction is 4 v_min_u32 with DPP operands inside rows of 16, then 4 v_readlane + 3 s_min_u32
 // (no NaN canonicalisation, which fminf would add to every step).
