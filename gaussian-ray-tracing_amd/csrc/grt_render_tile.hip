@@ -551,6 +551,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             bool lim_dirty = false;
             GRT_FRUSTUM(alive)
             uint32_t nact_ref = (uint32_t)__popcll(wave_ballot(alive)); // wanting lanes the frustum was fitted to
+            uint32_t nact_cur = nact_ref;                               // wanting lanes now (loop top)
             // frontier: slot i = lane i; free slot: (inf, kNoRoot)
             float fl = (lane == 0u) ? 0.0f : INFINITY;
             uint32_t fr = (lane == 0u) ? a.root_ref : kNoRoot;
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     const float ct_ = (lost != kKeyInvalid) ? key_t(lost) : t_hi_m;
                     const bool act = alive && (ct_ >= F);
                     const uint32_t nact = (uint32_t)__popcll(wave_ballot(act));
+                    nact_cur = nact;
                     if (nact == 0u) F = INFINITY; // nothing left to find: the pass is over
                     done = !(F < INFINITY);
                     if (!done && (nact * 2u <= nact_ref)) { // half of them have finished: re-fit the frustum
@@ -736,10 +738,22 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                           ((k0 == kKeyInvalid) || (k0 >= bagmin));
                         const uint64_t nm_ = bags ? wave_ballot(need) : 0ull;
                         if (!(cm_ | nm_)) break;
+#ifdef GRT_TILE_STOP
+                        if (!done) { // (experiment: a sweep also ENDS when fewer than GRT_TILE_STOP lanes can go on)
+                            const bool go_ = ((uint32_t)__popcll(cm_ | nm_) >= (sweep ? (uint32_t)GRT_TILE_STOP : ready_min)) ||
+                                             wave_any(can_ && (KPRESS != kKeyInvalid));
+                            if (!go_) break;
+                            sweep = true;
+                        }
+#else
                         if (!sweep) {
-                            sweep = ((uint32_t)__popcll(cm_ | nm_) >= ready_min) || wave_any(can_ && (KPRESS != kKeyInvalid));
+                            // (a tile down to a few wanting lanes never has ready_min of them ready: its last rays would go on
+                            //  gathering events they end before, until a window fills — half of the wanting lanes are enough)
+                            const uint32_t rmin_ = min(ready_min, max(1u, (nact_cur + 1u) >> 1));
+                            sweep = ((uint32_t)__popcll(cm_ | nm_) >= rmin_) || wave_any(can_ && (KPRESS != kKeyInvalid));
                             if (!sweep) break;
                         }
+#endif
                         if (!cm_) {
                             // ---- refill: one scan of the bags of the lanes in need; entry by entry, whatever is smaller
                             //      than the window's last key goes in (sorted insert) and the displaced last key takes
