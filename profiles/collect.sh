@@ -15,7 +15,7 @@ TAG=${1:-rXX}
 WL=${2:-C3}
 QUICK=${3:-}
 LABEL=${4:-}            # optional: suffix for a variant of the workload, the remaining arguments go to bench.py
-shift; shift; shift; shift || true   #   e.g. profiles/collect.sh r03 C3 "" sh3 --sh-degree 3
+for _ in 1 2 3 4; do shift 2>/dev/null || true; done   #   e.g. profiles/collect.sh r03 C3 "" sh3 --sh-degree 3
 BARGS="$@"
 R=$PWD
 export TMPDIR=/tmp

@@ -96,10 +96,11 @@ if "SQ_WAVES" in out and "SQ_INSTS_VALU" in out:
         v["raw_metric_of_the_saturating_microkernels_all_W"] = round(4 * cal["SQ_ACTIVE_INST_VALU"] / cal["SQ_WAVE_CYCLES"], 3)
     v["note"] = ("rocprofv3 --pmc of the same command.  The raw metric round 1 quoted as 'VALU busy' (n_waves x SQ_ACTIVE_INST_VALU / "
                  "SQ_WAVE_CYCLES) tops out at 2.0, not 1.0: the SIMD-32 retires a wave64 instruction every 2 cycles, so the VALU PIPE "
-                 "utilisation is half of it (valu_pipe_utilisation).  wave_time_split (same file) says where a wave's cycles go: ~43 % "
-                 "issuing, ~25 % stalled at issue, ~32 % in s_waitcnt; round 3 measured that neither hiding issue dependencies nor a "
-                 "fifth resident wave moves the frame by more than 3 % (DESIGN.md 6): what bounds the kernel is the work itself, 60 k "
-                 "instructions and ~250 dependent memory round trips per wave (calibration: profiles/calib/valu_calib.hip, dep_dist.hip)")
+                 "utilisation is half of it (valu_pipe_utilisation).  What a frame costs is its instruction count: adding work to every "
+                 "exact test (profiles/r03_sensitivity.json) gives +0.036 ms per 1000 VALU and +0.028 ms per 1000 SALU instructions per "
+                 "wave and 0.0009 ms per dependent scalar round trip, which reproduces the frame from these counters; round 3 took "
+                 "40.1 k -> ~37 k VALU and 20.2 k -> ~16 k SALU per wave out of the kernel (DESIGN.md 5.2, 6) "
+                 "(calibration: profiles/calib/valu_calib.hip, dep_dist.hip)")
     res["valu"] = v
 json.dump(res, open(os.path.join(here, f"{tag}_counters.json"), "w"), indent=1)
 tpath = os.path.join(here, "traffic.json")
