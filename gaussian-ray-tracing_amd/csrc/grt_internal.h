@@ -38,7 +38,7 @@ struct DevBvh {
     float4* qnodes = nullptr;  // [(n_prims-1) * 2 * kTileWide] the tree laid out per CHILD for the tile kernel
                                //   (grt_render_tile.hip: one lane tests one child box), kTileWide children per record:
                                //   child c of node i at [i*2W + 2c] = (lo.xyz, ref bits), [+1] = (hi.xyz, 0); unused: ref kNoRoot
-    float4* pbox = nullptr;    // [n_prims * 2] box of every sorted primitive, (lo.xyz,0)(hi.xyz,0): what a leaf-range
+    float4* pbox = nullptr;    // [n_prims * 2] box of every sorted primitive, (lo.xyz,0)(hi.xyz,r), r = bounding radius about the box centre: what a leaf-range
                                //   child expands to in the tile kernel (built only for the Gaussian BVH)
     uint32_t* level = nullptr; // [n_prims-1] refit pass in which each node was finished (kept when asked for: refit_lbvh)
     uint32_t* order = nullptr; // [n_prims] sorted position -> input primitive index
