@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t vote_eq_u32(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint64_t vote_lt_f32(float a, float b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_fcmp(a, b, 4); // FCMP_OLT
+    return __builtin_amdgcn_fcmpf(a, b, 4); // FCMP_OLT (fcmpf: the float form; fcmp is the double one)
 #else
     return a < b;
 #endif
