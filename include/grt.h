@@ -149,7 +149,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_HEAVY_THRESHOLD_X2 = 6 /* a unit is heavy when its cost exceeds value/2 x the median cost (default 4) */,
        GRT_OPT_HEAVY_CAP_DIV = 7      /* at most 1/value of the units go to the big-window kernel (default 8) */,
        /* tile kernel (GRT_OPT_KERNEL = 5) tuning; pixels never depend on these */
-       GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event before a compositing sweep starts, 1..64 (16) */,
+       GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event for a compositing sweep to start or go on (fewer when few lanes still want anything), 1..64 (24) */,
        GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (16) */,
        GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (32) */,
        GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */,

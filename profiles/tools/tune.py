@@ -14,7 +14,7 @@ def t():
     ms = []
     for _ in range(8): tr.render(p); ms.append(tr.last_kernel_ms())
     return float(np.median(ms))
-base = {grt.OPT_TILE_READY_MIN: 16, grt.OPT_TILE_BAND: 64, grt.OPT_TILE_LOOKAHEAD: 64, grt.OPT_TILE_RESERVE: 24, grt.OPT_SWIZZLE: 2, grt.OPT_COST_RADIUS: 4}
+base = {grt.OPT_TILE_READY_MIN: 24, grt.OPT_TILE_BAND: 64, grt.OPT_TILE_LOOKAHEAD: 64, grt.OPT_TILE_RESERVE: 24, grt.OPT_SWIZZLE: 2, grt.OPT_COST_RADIUS: 4}
 names = {grt.OPT_TILE_READY_MIN: "ready_min", grt.OPT_TILE_BAND: "band", grt.OPT_TILE_LOOKAHEAD: "look", grt.OPT_TILE_RESERVE: "reserve", grt.OPT_SWIZZLE: "swizzle", grt.OPT_COST_RADIUS: "cost_radius"}
 print("base", round(t(), 4))
 sweeps = {grt.OPT_TILE_READY_MIN: (4, 8, 12, 24, 32), grt.OPT_TILE_BAND: (16, 32, 96, 128, 192), grt.OPT_TILE_LOOKAHEAD: (16, 32, 96, 128, 192),
