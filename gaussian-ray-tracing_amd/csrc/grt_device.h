@@ -189,13 +189,30 @@ __device__ __forceinline__ bool piece_owns(uint32_t desc, float s, f3 o_g, f3 d_
     return own;
 }
 
+// expf for an argument <= 0: the device library's own sequence (x log2(e) in two floats, v_exp_f32 of the fraction, v_ldexp_f32)
+// without its two range checks — the overflow one cannot fire, and below -87 the scaling underflows to the same 0 the
+// check would return.  Bit-identical to expf on (-87, 0]; four VALU instructions fewer per particle inserted.
+__device__ __forceinline__ float exp_nonpos(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float ph = x * 0x1.715476p+0f;
+    float pl = __builtin_fmaf(x, 0x1.715476p+0f, -ph);
+    pl = __builtin_fmaf(x, 0x1.4ae0bep-26f, pl);
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+#else
+    return expf(x);
+#endif
+}
+
 // computeResponse — shaders/tracer.cuh:187-214, given o_g = A(o-mu), d_g = A d already formed
 __device__ __forceinline__ float response_from(const m33& A, f3 mu, f3 o, f3 d, f3 o_g, f3 d_g)
 {
     const float d_val = -dot3(o_g, d_g) / fmaxf(1e-6f, dot3(d_g, d_g));
     const f3 pos = add3(o, mul3s(d, d_val));
     const f3 p_g = matvec(A, sub3(mu, pos));
-    return expf(-0.5f * dot3(p_g, p_g));
+    return exp_nonpos(-0.5f * dot3(p_g, p_g));
 }
 
 // SHToRadiance + computeRadiance — shaders/tracer.cuh:216-264.  sh points at 16 float3 (48 floats).
