@@ -288,7 +288,7 @@ struct grt_ctx {
     float4 *d_prec = nullptr, *d_queue = nullptr; // d_queue: two queues (ping-pong between the stages)
     uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)
     int opt_bundle_rounds = 2; // bounce iterations traced by the wave-per-bundle kernel before the per-lane kernel finishes
-    int opt_bundle_budget = 1024;
+    int opt_bundle_budget = 896; // (C4 sweep, profiles/tools/tune_c4.py: 3.30 ms at 768..896, 3.40 at 1024, 4.1 at 640: below ~700 too many bundles end one ray per wave)
     int opt_lane_budget = 128;
     int opt_single_look = 256, opt_single_band = 256; // 1/1024
     uint32_t* d_heavy = nullptr;

@@ -150,8 +150,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_HEAVY_CAP_DIV = 7      /* at most 1/value of the units go to the big-window kernel (default 8) */,
        /* tile kernel (GRT_OPT_KERNEL = 5) tuning; pixels never depend on these */
        GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event for a compositing sweep to start or go on (fewer when few lanes still want anything), 1..64 (24) */,
-       GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (16) */,
-       GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (32) */,
+       GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (64) */,
+       GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (64) */,
        GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */,
        GRT_OPT_TILE_PRIO_DIV = 12     /* the heaviest 1/value of the tiles (by last frame's cost) run at raised wave priority; 0 = off */,
        GRT_OPT_COST_RADIUS = 13       /* scheduling feedback under a moving camera: a tile's cost is the largest of last frame's costs
@@ -165,7 +165,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          finishes whatever still bounces; 0..4, default 2.  Same image for every value */,
        GRT_OPT_BUNDLE_BUDGET = 17     /* work (steps + particles fetched + 2 x exact tests) a bundle may take before it is given up and its
                                          rays are traced one per wave (a bundle whose rays have spread too far to share work); default
-                                         1024, doubled for GRT_GLASS.  Same image for every value */,
+                                         896, doubled for GRT_GLASS.  Same image for every value */,
        GRT_OPT_SINGLE_LOOKAHEAD = 18  /* one-ray-per-wave mode: as GRT_OPT_TILE_LOOKAHEAD (default 256 = 25 %) */,
        GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
        GRT_OPT_SPLIT = 24             /* spatial splits: a proxy much longer than the typical one whose world box is mostly empty (a needle or
