@@ -152,6 +152,38 @@ def test_fisheye_exact_with_host_rays(tr):
     compare(out, ref)
 
 
+def test_axis_parallel_rays_with_signed_zero_directions(tr):
+    """The slab test folds the sign of a direction projection in by its SIGN BIT (grt_device.h: proxy_slabs_pre,
+    oracle/grt_oracle.c: proxy_slabs): projections that are exactly +0 or -0 — rays along the axes of unrotated Gaussians —
+    are where the two readings of 'negative' differ.  Oracle and kernel must agree on them, whatever the sign of the zero."""
+    import torch
+    acts, p, sc, op, _ = make_scene(23, 600, 32, 32, scale_boost=0.8)
+    acts = dict(acts)
+    acts["quat"] = np.tile(np.float32([1, 0, 0, 0]), (len(acts["pos"]), 1))  # unrotated: the slab normals are the axes' own
+    acts["pos"] = (np.round(acts["pos"] * 4.0) / 4.0).astype(np.float32)     # centres on a lattice the rays run through
+    sc.close()
+    sc = O.Scene(acts_to_particles(acts))
+    tr.upload(acts)
+    rays = []
+    zeros = (np.float32(0.0), np.float32(-0.0))
+    for axis in range(3):
+        for sgn in (1.0, -1.0):
+            for za in zeros:
+                for zb in zeros:
+                    for u in np.arange(-1.0, 1.01, 0.25):
+                        for v in np.arange(-1.0, 1.01, 0.25):
+                            o = np.zeros(3, np.float32); d = np.zeros(3, np.float32)
+                            o[axis] = -6.0 * sgn; o[(axis + 1) % 3] = u; o[(axis + 2) % 3] = v
+                            d[axis] = sgn; d[(axis + 1) % 3] = za; d[(axis + 2) % 3] = zb
+                            rays.append(np.concatenate([o, d]))
+    rays = np.float32(rays)
+    ref, cnt = sc.render_rays(op, rays)
+    out = tr.render_rays(p, torch.tensor(rays, device="cuda:0"))
+    assert cnt["hit_evals"] > len(rays)  # the rays do run through Gaussians
+    compare(out, ref)
+    sc.close()
+
+
 @pytest.mark.parametrize("mesh_type", [grt.MIRROR, grt.NORMAL, grt.GLASS])
 def test_mesh_sphere_modes(tr, mesh_type):
     acts, p, sc, op, center = make_scene(8, 5000, 128, 128, scale_boost=0.5, mesh_type=mesh_type)
