@@ -730,9 +730,16 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     }
                 }
                 if (!SINGLE && !dfs) {
+                    // a lane's next event may be composited when its key lies below ONE limit: the smallest of the front (as a
+                    // key: t < F <=> key < F's bits << 32, both non-negative), the lane's bag minimum and its cut-off.  The limit
+                    // changes once per trip of the outer loop (and after a refill); the test below runs once per compositing step
+                    // and once more per trip: one 64-bit compare instead of four compares (k0 = ~0, a free slot, is never below it).
+                    const uint64_t fkey_ = (uint64_t)__float_as_uint(F) << 32;
+                    uint64_t limk_ = (bagmin < lost) ? bagmin : lost;
+                    limk_ = (fkey_ < limk_) ? fkey_ : limk_;
                     while (true) {
-                        bool can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
-                        uint64_t cm_ = wave_ballot(can_);
+                        bool can_ = alive & (k0 < limk_);
+                        uint64_t cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
                         // a lane whose next final event sits in its bag needs a refill before it can go on
                         const bool need = bags && alive && (nb != 0u) && !can_ && (key_t(bagmin) < F) && (bagmin < lost) &&
                                           ((k0 == kKeyInvalid) || (k0 >= bagmin));
@@ -801,8 +808,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             // (the refill and the compositing step are two if-thens in a row, not the arms of an if / else:
                             //  the arms of a structurised if / else keep BOTH versions of the window alive, 27 register copies
                             //  per compositing step)
-                            can_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < bagmin) && (k0 < lost);
-                            cm_ = wave_ballot(can_);
+                            limk_ = (bagmin < lost) ? bagmin : lost;
+                            limk_ = (fkey_ < limk_) ? fkey_ : limk_;
+                            can_ = alive & (k0 < limk_);
+                            cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
                         }
                         if (!cm_) continue;
                         GRT_D(hit_evals, 1)
