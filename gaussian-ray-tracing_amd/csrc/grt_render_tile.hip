@@ -146,16 +146,29 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #define GRT_D(f, n)
 #endif
 
-// signed-float wave reductions (set-up only: ten of them per tile)
-__device__ __forceinline__ float wave_fmin(float v)
+// Signed-float wave reductions: eleven per frustum fit, and a tile re-fits its frustum every time half of its wanting lanes
+// have finished.  As `fminf(v, __shfl_xor(v, off))` each was six dependent LDS round trips (ds_bpermute) and eighteen VALU
+// operations with their NaN canonicalisation; here a float goes through an order-preserving integer key (sign bit
+// flipped for v >= 0, all bits for v < 0), the DPP integer minimum of grt_wave.h (wave_min / wave_min4: no LDS, four
+// reductions interleaved) and back.  The result is wave-uniform and the exact minimum / maximum as before.
+__device__ __forceinline__ uint32_t fkey(float f)
 {
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
-__device__ __forceinline__ float wave_fmax(float v)
+__device__ __forceinline__ float fkey_inv(uint32_t k)
 {
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
+    return __uint_as_float(k ^ ((uint32_t)((int32_t)~k >> 31) | 0x80000000u));
+}
+__device__ __forceinline__ float wave_fmin(float v) { return fkey_inv(__float_as_uint(wave_min(__uint_as_float(fkey(v))))); }
+__device__ __forceinline__ float wave_fmax(float v) { return fkey_inv(~__float_as_uint(wave_min(__uint_as_float(~fkey(v))))); }
+// (min a, max b, min c, max d) in one go
+__device__ __forceinline__ void wave_fminmax4(float a, float b, float c, float d, float& mna, float& mxb, float& mnc, float& mxd)
+{
+    float ra, rb, rc, rd;
+    wave_min4(__uint_as_float(fkey(a)), __uint_as_float(~fkey(b)), __uint_as_float(fkey(c)), __uint_as_float(~fkey(d)), ra, rb, rc, rd);
+    mna = fkey_inv(__float_as_uint(ra)); mxb = fkey_inv(~__float_as_uint(rb));
+    mnc = fkey_inv(__float_as_uint(rc)); mxd = fkey_inv(~__float_as_uint(rd));
 }
 __device__ __forceinline__ float uni(float v)
 {
@@ -452,9 +465,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
         // stays on the inner side of the plane through ITS origin), per-axis origin offsets, the origins' spread about oc
         // and the bounds of |d| (a bounced direction is a unit vector only up to rounding)
         float mL = 0.0f, mR = 0.0f, mB = 0.0f, mT = 0.0f, ofx = 0.0f, ofy = 0.0f, ofz = 0.0f, rmax = 0.0f, idmax = 1.0f, idmin = 1.0f;
-#define GRT_AXIS(M, C, IV, SH_, OF)                                                                        \
+#define GRT_AXIS(M, C, IV, SH_, OF, MN, MX)                                                                \
         {                                                                                                  \
-            const float mn_ = uni(wave_fmin((M) ? d.C : INFINITY)), mx_ = uni(wave_fmax((M) ? d.C : -INFINITY)); \
+            const float mn_ = uni(MN), mx_ = uni(MX);                                                      \
             SH_ = mx_ < -1e-20f;                                                                           \
             IV = (mn_ > 1e-20f) ? (1.0f - 1e-6f) / mx_ : (SH_ ? (1.0f - 1e-6f) / mn_ : 0.0f);              \
             IV = uni(pk_ * IV);                                                                            \
@@ -482,9 +495,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             const float ida = 1.0f / fmaxf(da, 1e-6f);                                                     \
             const float tu = dot3(d, uu) * ida, tv = dot3(d, vv) * ida;                                    \
             /* a tile wider than ~75 degrees (tiny fisheye frames) gets no culling at all: every box passes */ \
-            const float pk_ = (uni(wave_fmin((M) ? da : 1.0f)) >= 0.25f) ? 1.0f : 0.0f;                    \
-            float tu0 = uni(wave_fmin((M) ? tu : INFINITY)), tu1 = uni(wave_fmax((M) ? tu : -INFINITY));   \
-            float tv0 = uni(wave_fmin((M) ? tv : INFINITY)), tv1 = uni(wave_fmax((M) ? tv : -INFINITY));   \
+            float mnx_, mxx_, mny_, mxy_, mnz_, mxz_, damin_, spare_;                                      \
+            wave_fminmax4((M) ? d.x : INFINITY, (M) ? d.x : -INFINITY, (M) ? d.y : INFINITY, (M) ? d.y : -INFINITY, mnx_, mxx_, mny_, mxy_); \
+            wave_fminmax4((M) ? d.z : INFINITY, (M) ? d.z : -INFINITY, (M) ? da : 1.0f, -INFINITY, mnz_, mxz_, damin_, spare_); \
+            (void)spare_;                                                                                  \
+            const float pk_ = (uni(damin_) >= 0.25f) ? 1.0f : 0.0f;                                         \
+            float tu0, tu1, tv0, tv1;                                                                      \
+            wave_fminmax4((M) ? tu : INFINITY, (M) ? tu : -INFINITY, (M) ? tv : INFINITY, (M) ? tv : -INFINITY, tu0, tu1, tv0, tv1); \
+            tu0 = uni(tu0); tu1 = uni(tu1); tv0 = uni(tv0); tv1 = uni(tv1);                                \
             tu0 -= 1e-4f * (1.0f + fabsf(tu0)); tu1 += 1e-4f * (1.0f + fabsf(tu1));                        \
             tv0 -= 1e-4f * (1.0f + fabsf(tv0)); tv1 += 1e-4f * (1.0f + fabsf(tv1));                        \
             /* unit normals (the leaf step sets a bounding sphere's radius against them); pk_ = 0: no plane at all */ \
@@ -492,9 +510,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             GRT_PNORM(pR, tu1 * ax.x - uu.x, tu1 * ax.y - uu.y, tu1 * ax.z - uu.z)                             \
             GRT_PNORM(pB, vv.x - tv0 * ax.x, vv.y - tv0 * ax.y, vv.z - tv0 * ax.z)                             \
             GRT_PNORM(pT, tv1 * ax.x - vv.x, tv1 * ax.y - vv.y, tv1 * ax.z - vv.z)                             \
-            GRT_AXIS(M, x, ivx, shx, ofx)                                                                  \
-            GRT_AXIS(M, y, ivy, shy, ofy)                                                                  \
-            GRT_AXIS(M, z, ivz, shz, ofz)                                                                  \
+            GRT_AXIS(M, x, ivx, shx, ofx, mnx_, mxx_)                                                      \
+            GRT_AXIS(M, y, ivy, shy, ofy, mny_, mxy_)                                                      \
+            GRT_AXIS(M, z, ivz, shz, ofz, mnz_, mxz_)                                                      \
             if (BUNDLE) {                                                                                  \
                 GRT_POFF(M, pL, mL) GRT_POFF(M, pR, mR) GRT_POFF(M, pB, mB) GRT_POFF(M, pT, mT)            \
                 const float r_ = length3(sub3(o, oc)), ld_ = length3(d);                                   \
