@@ -32,7 +32,8 @@ def shift_macro(ks):
         outs = ', '.join(f'[k{i}] "+v"(k{i})' for i in range(lo, hi + 1)) + ', [sv] "=&s"(sv_)'
         ins = '[m] "s"(m_)' + (f', [k{hi+1}] "v"(k{hi+1})' if hi + 1 < ks else '')
         guard = '' if lo == 0 else f'if (wave_any(k{lo} != kKeyInvalid)) /* nothing above an empty slot */ '
-        blocks.append('        ' + guard + 'asm volatile(' + ' '.join(lines) + '\n                     : ' + outs + '\n                     : ' + ins + ');')
+        # (s_and_saveexec_b64 writes SCC: the compiler must not keep a compare result alive across the block)
+        blocks.append('        ' + guard + 'asm volatile(' + ' '.join(lines) + '\n                     : ' + outs + '\n                     : ' + ins + '\n                     : "scc");')
         lo = hi + 1
     body = '\n'.join(blocks)
     return ('#define SLOT_SHIFT_ALL(MASK)  \\\n    {  \\\n        const uint64_t m_ = (MASK);  \\\n        uint64_t sv_;  \\\n'
@@ -71,7 +72,7 @@ def insert_macro(ks):
         guard = 'if (go_ != 0ull) ' if lo == 0 else f'if (go_ != 0ull && wave_any(k{lo-1} != kKeyInvalid)) '
         if hi == ks - 1:
             guard = '' if lo == 0 else f'if (wave_any(k{lo-1} != kKeyInvalid)) '
-        blocks.append('        ' + guard + 'asm volatile(' + ' '.join(lines) + '\n                     : ' + outs + '\n                     : ' + ins + ');')
+        blocks.append('        ' + guard + 'asm volatile(' + ' '.join(lines) + '\n                     : ' + outs + '\n                     : ' + ins + '\n                     : "scc");')
         hi = lo - 1
     body = '\n'.join(blocks)
     nm = chunk(ks) + 1
