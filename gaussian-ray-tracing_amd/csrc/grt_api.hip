@@ -148,6 +148,15 @@ __device__ __forceinline__ PieceGrid piece_grid(const float* __restrict__ scale,
     return g;
 }
 
+// 64-bit sum of a 32-bit array (the piece total: the exclusive scan beside it runs in 32 bits and could wrap)
+__global__ void k_sum_u32(const uint32_t* __restrict__ v, uint64_t n, unsigned long long* __restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += v[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63u) == 0u && acc) atomicAdd(out, acc);
+}
+
 __global__ void k_piece_counts(const float* __restrict__ scale, const float* __restrict__ quat, const float* __restrict__ s_arr,
                                const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, float tau,
                                uint32_t* __restrict__ counts)
@@ -451,6 +460,7 @@ int grt_create(grt_ctx** out, int device)
         (e = hipMalloc(&c->d_n_heavy, sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc(&c->d_err, sizeof(uint32_t))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
         (e = hipHostMalloc(&c->h_ovf_used, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_err, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_ovf, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming)) != hipSuccess) {
         g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
@@ -459,6 +469,7 @@ int grt_create(grt_ctx** out, int device)
         return GRT_ERR_HIP;
     }
     *c->h_ovf_used = 0;
+    *c->h_err = 0;
     *out = c;
     return GRT_OK;
 }
@@ -512,6 +523,7 @@ static void free_slot_state(grt_ctx* c)
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
     if (c->h_ovf_used) (void)hipHostFree(c->h_ovf_used);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_ovf) (void)hipEventDestroy(c->ev_ovf);
@@ -652,6 +664,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     c->gbvh.n_prims = 0;
     c->gbvh.root_ref = kNoRoot;
     c->gbvh.height = 0;
+    c->has_pieces = false;
     if (n == 0) { c->built = true; return GRT_OK; }
     // proxy half-width s = sqrtf(2 logf(opacity/alpha_min)) on the HOST, as the reference does
     // (src/GaussianTracer.cpp:306) — keeps the libm-dependent value identical to the host libm's.
@@ -711,7 +724,20 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
             if (e == hipSuccess) e = hipMemcpyAsync(&last_cnt, d_cnt + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->err = std::string("grt_build_bvh: split scan: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
-            const uint64_t total = (uint64_t)last_off + last_cnt;
+            uint64_t total = (uint64_t)last_off + last_cnt;
+            // (the scan runs in 32 bits: 512 pieces per particle times 2^26 particles could wrap it — the true total is summed in
+            //  64 bits beside it, and a scene whose pieces would not fit the leaf index keeps whole proxies)
+            if (rc == GRT_OK) {
+                unsigned long long* d_tot = nullptr;
+                unsigned long long h_tot = 0;
+                if ((e = hipMalloc(&d_tot, sizeof(*d_tot))) == hipSuccess && (e = hipMemsetAsync(d_tot, 0, sizeof(*d_tot), c->stream)) == hipSuccess) {
+                    hipLaunchKernelGGL(k_sum_u32, dim3(std::min<uint32_t>((uint32_t)((n + 255) / 256), 1024u)), dim3(256), 0, c->stream, d_cnt, n, d_tot);
+                    if ((e = hipMemcpyAsync(&h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, c->stream)) == hipSuccess) e = hipStreamSynchronize(c->stream);
+                }
+                (void)hipFree(d_tot);
+                if (e != hipSuccess) { c->err = std::string("grt_build_bvh: piece total: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
+                else total = h_tot;
+            }
             // (a scene where splitting adds less than 2 % of primitives has no population of needles and sheets to speak of:
             //  it keeps whole proxies — size classes deal with the odd large one — and the kernels without the piece logic)
             if (rc == GRT_OK && total > (uint64_t)n + n / 50u && total <= (uint64_t)kLeafIndexMask) {
@@ -755,11 +781,12 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         else (void)hipEventElapsedTime(&c->build_ms, c->ev0, c->ev1);
     }
     (void)hipFree(d_s); (void)hipFree(d_lo); (void)hipFree(d_hi);
+    const bool have_pieces = d_owner != nullptr;
     (void)hipFree(d_plo); (void)hipFree(d_phi); (void)hipFree(d_cnt); (void)hipFree(d_offs); (void)hipFree(d_owner); (void)hipFree(d_desc); (void)hipFree(d_scan_tmp);
     c->have_timing = false;
     c->cost_valid = false;
     c->erec_valid = false;
-    if (rc == GRT_OK) { c->built = true; c->built_leaf_max = c->opt_leaf_max; }
+    if (rc == GRT_OK) { c->built = true; c->built_leaf_max = c->opt_leaf_max; c->has_pieces = have_pieces; }
     return rc;
 }
 
@@ -968,7 +995,7 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
     a->pbox = sc->gbvh.pbox;
     a->root_ref = sc->gbvh.root_ref;
     a->n_prox = sc->gbvh.n_prims;
-    a->has_pieces = sc->gbvh.n_prims > sc->n_hittable ? 1u : 0u;
+    a->has_pieces = sc->has_pieces ? 1u : 0u; // set by the build that made pieces (not inferred from counts: build_lbvh drops NaN boxes)
     a->color0 = sc->d_color0;
     a->sh = sc->d_sh;
     a->mnodes = sc->mbvh.nodes;
@@ -1280,6 +1307,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         if (hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s) == hipSuccess) c->ovf_zeroed = true;
         tail = true;
     }
+    // the sticky error word as the frame (and k_check_costs) left it -> pinned host word, on the frame's stream: grt_sync
+    // reads it behind ev_tail without a blocking null-stream copy (which waited for every other frame slot's stream too)
+    if (hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess) tail = true;
     if (tail && hipEventRecord(c->ev_tail, s) == hipSuccess) { c->tail_pending = true; c->tail_stream = s; }
     return rc;
 }
@@ -1369,13 +1399,20 @@ int grt_render_rays(grt_ctx* c, const grt_params* p, const float* d_rays, uint64
 // The sticky device error word (RenderArgs::err_word): a wave that had to give up on a ray — watchdog, depth-first stack
 // guard, two passes without progress — ORs its reason in, in EVERY kernel variant (counters on or off).  Read (and
 // cleared) at the synchronising entry points; the reference turns traversal trouble into exceptions the same way
-// (OptiX exception flags, src/GaussianTracer.cpp:114-119; src/Exception.h:31-80).  The stream must be idle.
+// (OptiX exception flags, src/GaussianTracer.cpp:114-119; src/Exception.h:31-80).
 static int check_device_error(grt_ctx* c)
 {
-    uint32_t w = 0;
-    CHK(c, hipMemcpy(&w, c->d_err, sizeof(w), hipMemcpyDeviceToHost));
+    // the last frame may have gone to ANY stream (the caller's, a view's): what ran behind it — k_check_costs, which
+    // turns the tile kernel's give-up reasons into the error word, and the copy of the word to h_err — is finished once
+    // ev_tail is.  (Waiting for c->stream and ev1 alone returned GRT_OK for a frame on a non-blocking side stream whose
+    // tiles had given up: ADVICE r03.)
+    if (c->tail_pending) CHK(c, hipEventSynchronize(c->ev_tail));
+    const uint32_t w = *(volatile uint32_t*)c->h_err;
     if (!w) return GRT_OK;
-    CHK(c, hipMemset(c->d_err, 0, sizeof(w)));
+    hipStream_t s = c->tail_stream ? c->tail_stream : c->stream;
+    CHK(c, hipMemsetAsync(c->d_err, 0, sizeof(w), s)); // stream-ordered before the next frame's kernels (do_launch waits on ev_tail)
+    *c->h_err = 0;
+    if (hipEventRecord(c->ev_tail, s) == hipSuccess) { c->tail_pending = true; c->tail_stream = s; }
     c->err = std::string("render: a wave gave up on live rays (pixels are missing hits):") +
              ((w & kErrWatchdog) ? " step watchdog expired;" : "") + ((w & kErrStack) ? " depth-first overflow stack full;" : "") +
              ((w & kErrStall) ? " two passes without progress;" : "");

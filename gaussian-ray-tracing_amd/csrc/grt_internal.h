@@ -222,6 +222,7 @@ struct grt_ctx {
     float gm_diag = 0.f;          // geometric mean of the proxies' box diagonals (grt_build_bvh)
     int opt_split = 8;            // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off)
     uint32_t n_hittable = 0;      // particles with opacity > alpha_min (BVH primitives = these, or their pieces)
+    bool has_pieces = false;      // the current Gaussian BVH holds pieces of split proxies (the PIECES kernel instantiations)
     float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags
     uint32_t* d_ovf_next = nullptr;
     uint32_t ovf_chunks = 0;
@@ -235,6 +236,7 @@ struct grt_ctx {
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)
+    uint32_t* h_err = nullptr;    // pinned copy of it, refreshed behind every frame on the frame's stream (read after ev_tail)
     hipStream_t tail_stream = nullptr; // stream the post-frame work (next order, zeroing) was queued on
     hipEvent_t ev_tail = nullptr;
     bool tail_pending = false;

@@ -118,6 +118,27 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 // Checking build (make EXTRA=-DGRT_TILE_CHECK, never shipped): stall_exits counts violated invariants (an event turning
 // up below the front: +1 per lane; frontier entries not conserved by a rebalance: +1000 per lane) and, when a float
 // frame is rendered, row 0 of it receives the (t, 2 id + exit, T) log of the events lane GRT_TILE_CHECK_LANE composites.
+// Experiment switch (never shipped; profiles/r04_experiments_log.md): hardware reciprocal / reciprocal square root (1 ulp) in the
+// frustum fit instead of the correctly rounded divisions and square roots.  Bit 0: the per-lane 1 / (d . axis); bit 1: the
+// plane normals; bit 2: the per-axis slab bounds.  0 = the exact arithmetic that ships.
+#ifndef GRT_FIT_APPROX
+#define GRT_FIT_APPROX 0
+#endif
+#if GRT_FIT_APPROX & 1
+#define GRT_FIT_RCP1(x) __builtin_amdgcn_rcpf(x)
+#else
+#define GRT_FIT_RCP1(x) (1.0f / (x))
+#endif
+#if GRT_FIT_APPROX & 2
+#define GRT_FIT_NRM(p, x) ((p) * __builtin_amdgcn_rsqf(x))
+#else
+#define GRT_FIT_NRM(p, x) ((p) / sqrtf(x))
+#endif
+#if GRT_FIT_APPROX & 4
+#define GRT_FIT_DIV4(a, x) ((a) * __builtin_amdgcn_rcpf(x))
+#else
+#define GRT_FIT_DIV4(a, x) ((a) / (x))
+#endif
 #ifndef GRT_TILE_CHECK_LANE
 #define GRT_TILE_CHECK_LANE 0u
 #endif
@@ -151,6 +172,11 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 // operations with their NaN canonicalisation; here a float goes through an order-preserving integer key (sign bit
 // flipped for v >= 0, all bits for v < 0), the DPP integer minimum of grt_wave.h (wave_min / wave_min4: no LDS, four
 // reductions interleaved) and back.  The result is wave-uniform and the exact minimum / maximum as before.
+// NaN: unlike fminf / fmaxf the integer key does not drop it (a NaN would win the reduction and void the frustum for the
+// whole tile).  No NaN reaches these reductions: they are fed from the rays of lanes with `alive`, which implies
+// have_ray, i.e. length(d) > 0.1 (the reference's loop guard, shaders/tracer.cu:59 — false for a NaN direction, which is
+// how a bounce off a zero shading normal ends), with origins that are the eye or a finite mesh hit point
+// (tests/test_gpu_parity.py::test_mesh_with_zero_normals_nan_bounce_directions).
 __device__ __forceinline__ uint32_t fkey(float f)
 {
     const uint32_t b = __float_as_uint(f);
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
         {                                                                                                  \
             const float mn_ = uni(MN), mx_ = uni(MX);                                                      \
             SH_ = mx_ < -1e-20f;                                                                           \
-            IV = (mn_ > 1e-20f) ? (1.0f - 1e-6f) / mx_ : (SH_ ? (1.0f - 1e-6f) / mn_ : 0.0f);              \
+            IV = (mn_ > 1e-20f) ? GRT_FIT_DIV4(1.0f - 1e-6f, mx_) : (SH_ ? GRT_FIT_DIV4(1.0f - 1e-6f, mn_) : 0.0f); \
             IV = uni(pk_ * IV);                                                                            \
             if (BUNDLE) { /* the origin nearest to the box side the rays enter through */                  \
                 const float dl_ = o.C - oc.C;                                                              \
@@ -486,13 +512,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #define GRT_PNORM(P, X, Y, Z)                                                                              \
         {                                                                                                  \
             const float x_ = (X), y_ = (Y), z_ = (Z);                                                      \
-            const float il_ = pk_ / sqrtf(__builtin_fmaf(x_, x_, __builtin_fmaf(y_, y_, z_ * z_)));       \
+            const float il_ = GRT_FIT_NRM(pk_, __builtin_fmaf(x_, x_, __builtin_fmaf(y_, y_, z_ * z_))); \
             P##x = uni(x_ * il_); P##y = uni(y_ * il_); P##z = uni(z_ * il_);                              \
         }
 #define GRT_FRUSTUM(M)                                                                                     \
         {                                                                                                  \
             const float da = dot3(d, ax);                                                                  \
-            const float ida = 1.0f / fmaxf(da, 1e-6f);                                                     \
+            const float ida = GRT_FIT_RCP1(fmaxf(da, 1e-6f));                                              \
             const float tu = dot3(d, uu) * ida, tv = dot3(d, vv) * ida;                                    \
             /* a tile wider than ~75 degrees (tiny fisheye frames) gets no culling at all: every box passes */ \
             float mnx_, mxx_, mny_, mxy_, mnz_, mxz_, damin_, spare_;                                      \
@@ -1124,7 +1150,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             for (int q_ = 0; q_ < GRT_PROBE_VIND; q_++)
                                 asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pr0_), "+v"(pr1_));
 #pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_SALU; q_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps_));
+                            for (int q_ = 0; q_ < GRT_PROBE_SALU; q_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps_) : : "scc");
 #pragma unroll
                             for (int q_ = 0; q_ < GRT_PROBE_NOP; q_++) asm volatile("s_nop 1");
 #pragma unroll

@@ -204,6 +204,34 @@ def test_mesh_sphere_modes(tr, mesh_type):
         assert rc["segments"] > rc["rays"]
 
 
+@pytest.mark.parametrize("mesh_type", [grt.MIRROR, grt.GLASS])
+def test_mesh_with_zero_normals_nan_bounce_directions(tr, mesh_type):
+    """A mesh patch whose vertex normals are all zero interpolates to a NaN shading normal (normalize(0),
+    shaders/tracer.cuh:167-185), so the bounced direction is NaN and the reference's loop guard `length(dir) > 0.1`
+    (shaders/tracer.cu:59) ends the ray.  Such a ray must end HERE too without taking the other rays of its tile / bundle
+    with it (the bundle frustum's wave reductions do not ignore NaN; the guard is what keeps NaN out of them):
+    every pixel, the NaN ones' neighbours included, must match the oracle, and all pixels must be finite."""
+    acts, p, sc, op, center = make_scene(8, 5000, 128, 128, scale_boost=0.5, mesh_type=mesh_type, max_bounces=4)
+    pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+    v, n, f = grt.sphere_mesh(pos, tess_u=48, tess_v=24)
+    n = n.copy()
+    front = (v[:, 2] - pos[2] > 0.2) & (np.abs(v[:, 0] - pos[0]) < 0.12)  # a band of the side that faces the camera
+    assert 20 < front.sum() < len(v) // 2
+    n[front] = 0.0
+    tr.upload(acts)
+    tr.set_meshes([(v, n, f)])
+    sc.set_mesh(v, n, f)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    tr.set_meshes([])
+    ref_u8, ref_f32, rc = sc.render(op)
+    assert np.isfinite(ref_f32).all() and bool(np.isfinite(f32.cpu().numpy()).all())
+    compare(f32, ref_f32, u8, ref_u8)
+    assert cnt["segments"] == rc["segments"] and cnt["stall_exits"] == 0
+
+
 def test_two_meshes_plane_and_sphere_mirror_bounce_cap(tr):
     acts, p, sc, op, center = make_scene(9, 3000, 96, 96, scale_boost=0.5, mesh_type=grt.MIRROR, max_bounces=2)
     eye = np.float32([0, 0, 3])

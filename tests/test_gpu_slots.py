@@ -179,6 +179,34 @@ def test_watchdog_sets_the_sticky_error_word_in_the_production_kernel():
     tr.close(); sc.close()
 
 
+def test_watchdog_is_reported_for_a_frame_on_a_side_stream():
+    """the tile kernel's give-up reasons reach the error word through k_check_costs, which is queued BEHIND the
+    frame on the frame's own stream.  A frame rendered on a non-blocking torch side stream must still be reported by the
+    grt_sync that follows it (it used to wait for the context's stream and the frame's last kernel only, so the error came
+    one call late, or never), and without anything else synchronising the device in between."""
+    import torch
+    acts, p, sc, op, _ = make_scene(25, 20000, 128, 96, scale_boost=0.4)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ref8, _ = tr.render(p)
+        tr.check()
+        ref8 = ref8.clone()
+        tr.set_option(grt.OPT_MAX_ITERS, 3)
+        tr.render(p)
+        with pytest.raises(grt.GrtError) as ei:
+            tr.check()  # the very next sync, on the side stream's frame
+        assert ei.value.code == grt.ERR_LIMIT and "watchdog" in str(ei.value)
+        tr.check()  # cleared
+        tr.set_option(grt.OPT_MAX_ITERS, 0)
+        ok8, _ = tr.render(p)
+        tr.check()
+        side.synchronize()
+        assert bool((ok8 == ref8).all())
+    tr.close(); sc.close()
+
+
 def test_update_meshes_checks_the_topology_per_mesh():
     """grt_update_meshes re-fits the tree built by grt_set_meshes: it must refuse anything but the same meshes moved —
     per-mesh counts (two meshes that swap sizes keep the totals) and the face indices themselves."""
