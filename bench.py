@@ -68,8 +68,16 @@ def kernel_name(variant, with_mesh, sh_degree, leaf_max=4, pieces=False):
     return f"grt::k_render_stream<false, {sh}, {mesh}>"
 
 
+def contract_bytes(cnt, pixels, sh_degree, float_out=False):
+    """SURVEY §8(d)'s algorithmic bytes per launch, the figure `roofline.achieved` / `roofline.frac` are computed from:
+    B_alg = H * B_hit + V * B_node + P * B_out with H = consumed hit evaluations, B_hit = 44 + 12 (deg + 1)^2 (56 B at
+    degree 0, 236 B at degree 3), V = BVH node visits (one 32-B child box per lane that tests it), P = pixels written
+    (3 B, + 12 B with the float frame)."""
+    return (cnt["hit_evals"] * (44 + 12 * (sh_degree + 1) ** 2) + cnt["node_visits"] * 32 + pixels * (3 + (12 if float_out else 0)))
+
+
 def algorithmic_bytes(cnt, pixels, sh_degree, float_out=False):
-    """Bytes the kernel's algorithm needs per frame: every BVH child box / proxy record at the
+    """`roofline.frac_as_fetched`: bytes at the granularity the kernel fetches them: every BVH child box / proxy record at the
     granularity the kernel fetches it (the counter is in 16-B units) — tile kernel: a child box is 32 B per LANE that
     tests it, a proxy record + its eye record 128 B per WAVE; streaming kernel: a 4-wide node 128 B, a proxy record +
     eye record 80 B, per wave — plus, for every consumed hit, its colour (16 B at degree 0, 192 B of SH above), and
@@ -173,6 +181,8 @@ def main():
     ap.add_argument("--split", type=int, default=-1, help="GRT_OPT_SPLIT (piece length of the spatial splits, quarters of the typical proxy diagonal; 0 = off; -1 = library default)")
     ap.add_argument("--tile", type=int, default=TILE, help="edge of the screen tiles dealt round-robin to the ranks (multiple of 16)")
     ap.add_argument("--band-abs", type=int, default=-1, help="GRT_OPT_TILE_BAND_ABS (-1 = library default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
+                    help="grt_set_option(ID, VALUE) on every frame slot (tuning sweeps; include/grt.h lists the options), repeatable")
     ap.add_argument("--dump", default=None, help="write the frame as .npy (rank 0)")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one process, one GPU: do the work of ONE rank of an N-rank run (tile list, frame slots, "
@@ -243,6 +253,9 @@ def main():
         t.set_option(grt.OPT_KERNEL, args.kernel)
         if args.band_abs >= 0:
             t.set_option(grt.OPT_TILE_BAND_ABS, args.band_abs)
+        for kv in args.opt:
+            k_, v_ = kv.split("=")
+            t.set_option(int(k_), int(v_))
         trs.append(t)
     tr = trs[0]
     setup_s = (time.time() - t0) / n_ctx
@@ -359,6 +372,32 @@ def main():
             loop.step(0)
             kern_ms.append(trs[0].last_kernel_ms())
         kern_ms = kern_ms[1:]
+    # ---- a timed leg under a MOVING camera (one GPU): the same K frames, the eye orbiting the look-at point by 1.5 degrees per
+    #      frame, every frame synchronised like `value`'s — eye records rebuilt, the previous frame's costs ordering a different
+    #      frame, the feedback kernels behind every frame.  The headline repeats one view (a frame that repeats the last one keeps
+    #      its launch order and collects no costs); this is the same measurement for a viewer in motion: `value_orbit`.
+    elapsed_orbit = None
+    if extra and t_world == 1 and not force:
+        eye0 = np.float32(list(p.eye)) - center
+
+        def orbit_params(i):
+            ang = np.deg2rad(1.5 * (i + 1))
+            eye = center + np.float32([eye0[0] * np.cos(ang) + eye0[2] * np.sin(ang), eye0[1], -eye0[0] * np.sin(ang) + eye0[2] * np.cos(ang)])
+            return grt.default_params(W, H, center, sh_degree=args.sh_degree, fisheye=fisheye, mesh_type=grt.MIRROR,
+                                      max_bounces=max_bounces, eye=tuple(float(x) for x in eye))
+        qs = [orbit_params(i) for i in range(args.warmup + args.steps)]
+        for q in qs[:args.warmup]:
+            one_frame(q=q)
+            tr.sync()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for q in qs[args.warmup:]:
+            one_frame(q=q)
+            tr.last_kernel_ms()  # waits for the frame, as the synchronised loop of `value` does
+        torch.cuda.synchronize()
+        elapsed_orbit = time.perf_counter() - ts
+        one_frame(); one_frame()
+        tr.sync()
     other = None
     if D_other:
         lp2 = make_loop(D_other)
@@ -384,7 +423,8 @@ def main():
         value_sync, value_pipe = (value, value_other) if D == 1 else (value_other, value)
         # roofline of the dominant kernel: this rank's launch
         pix_mine = W * H if t_world == 1 else my_cnt * TILE * TILE
-        b_alg = algorithmic_bytes(cnt, pix_mine, args.sh_degree)
+        b_alg = contract_bytes(cnt, pix_mine, args.sh_degree)       # H * B_hit + V * 32 + P * 3
+        b_fetch = algorithmic_bytes(cnt, pix_mine, args.sh_degree)  # as fetched (records are shared by a wave: below the floor)
         b_min = cnt["hit_evals"] * (44 + 12 * (args.sh_degree + 1) ** 2) + pix_mine * 3  # SURVEY §8(d) floor
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
         traffic = valu = traffic_source = None
@@ -403,6 +443,8 @@ def main():
         out = {
             "metric": "Mrays/s (+ ms/frame) @1080p, 1M-Gaussian PLY", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "value_orbit": None if elapsed_orbit is None else round(rays_per_frame * args.steps / elapsed_orbit / 1e6, 3),
+            "ms_per_step_orbit": None if elapsed_orbit is None else round(elapsed_orbit / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n}-Gaussian synthetic 3DGS scene (seed {seed}), {W}x{H} "
                                    f"{'fisheye' if fisheye else 'pinhole'}, SH degree {args.sh_degree}"
@@ -431,7 +473,7 @@ def main():
                        "fetched_record_bytes_per_ray": round(16 * tot["rec_fetches"] / max(tot["segments"], 1), 1),
                        "stall_exits": tot["stall_exits"],
                        "bvh_height": info["height"], "n_proxies": info["n_proxies"], "n_bvh_primitives": info["n_primitives"], "bvh_build_ms": round(info["build_ms"], 2),
-                       "setup_s": round(setup_s, 2), "kernel_variant": args.kernel,
+                       "setup_s": round(setup_s, 2), "kernel_variant": args.kernel, "options": args.opt or None,
                        "scheduling": "8x8 tiles launched heaviest-first from the previous frame's per-tile cost "
                                      "(steady state of an interactive viewer); kernel_ms_cold / frame_ms_cold (wall, synchronised): a frame with no "
                                      "previous costs, tiles ordered by projected particle counts; kernel_ms_cold_screen_order: the same in screen order; "
@@ -445,8 +487,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name(args.kernel, with_mesh, args.sh_degree, pieces=info["n_primitives"] > info["n_proxies"]), "algorithmic_bytes_per_launch": int(b_alg),
+                         "formula": "SURVEY 8(d): H * (44 + 12 (deg + 1)^2) + V * 32 + P * 3, H = consumed hit evaluations, V = child boxes tested, "
+                                    "P = pixels; / kernel_ms (HIP events on the launch stream) / 8 TB/s",
                          "floor_bytes_per_launch": int(b_min),
                          "floor_frac": round(b_min / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "as_fetched_bytes_per_launch": int(b_fetch),
+                         "frac_as_fetched": round(b_fetch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "kernel_ms_median": round(float(np.median(kern_ms)), 4), "kernel_ms_min": round(float(np.min(kern_ms)), 4),
                          "valu_issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -464,7 +511,8 @@ def main():
 def cpu_baseline(acts, p, mesh, W, H):
     """The CPU oracle (oracle/grt_oracle.c, kind 'port': the reference itself needs OptiX and cannot run on a
     CPU) on a bounded sample of the same workload: the whole frame up to 1080p, the centred quarter-area window of it
-    above (about 10-30 s of CPU work on the GPU box's 16 cores)."""
+    above (about 10-30 s of CPU work), on every core the process may run on (sched_getaffinity; `nproc` = os.cpu_count() is printed
+    beside the thread count actually used)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
@@ -474,7 +522,7 @@ def cpu_baseline(acts, p, mesh, W, H):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)  # the GPU box's CPU share for one GPU
+    nproc = os.cpu_count() or cores  # all host cores the process may run on, nproc printed beside them
     sc = O.Scene(acts_to_particles(acts))
     if mesh is not None:
         sc.set_mesh(*mesh)
@@ -484,7 +532,7 @@ def cpu_baseline(acts, p, mesh, W, H):
     _, _, c = sc.render(to_oracle_params(p), window=win, threads=cores, want_u8=True, want_f32=False)
     dt = time.perf_counter() - t0
     sc.close()
-    return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "nproc": nproc, "threads": cores, "kind": "port",
             "sample": f"{'whole' if (cw, ch) == (W, H) else 'centred'} {cw}x{ch} window of the same frame ({c['segments']} rays, {dt:.1f} s); "
                       f"full-frame estimate {W * H / (c['segments'] / dt) * 1e3:.0f} ms/frame",
             "hit_evals_per_ray": round(c["hit_evals"] / max(c["segments"], 1), 2)}

@@ -422,7 +422,7 @@ __global__ void k_check_costs(const uint32_t* __restrict__ cost, uint32_t n, uin
     uint32_t e = 0;
     if (c & kCostStackBit) e |= kErrStack;
     if (c & kCostStallBit) e |= kErrStall;
-    if ((c & ~(kCostStackBit | kCostStallBit)) > max_iters) e |= kErrWatchdog;
+    if ((c & kCostStepsMask) > max_iters) e |= kErrWatchdog; // (bits 27-28: the tile ran as parts, grt_internal.h)
     if (e) atomicOr(err_word, e);
 }
 
@@ -603,6 +603,8 @@ int grt_set_option(grt_ctx* c, int option, int value)
     }
     else if (option == GRT_OPT_MAX_ITERS) { c->opt_max_iters = std::max(0, value); }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
+    else if (option == GRT_OPT_TILE_PARTS2_X2) { c->opt_tile_parts2_x2 = std::min(1 << 20, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_TILE_PARTS4_X2) { c->opt_tile_parts4_x2 = std::min(1 << 20, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
@@ -1018,6 +1020,8 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // which is what makes last frame's cost a good predictor; the first frame (or any change of size / mode) runs in
 // the default XCD-chunked order.
 // launch order of the units from the costs the last frame left in d_cost (dilated for full-frame launches)
+static uint32_t parts_extra_cap(uint32_t n_units) { return n_units / 4u + 64u; } // launch entries beyond one per tile
+
 static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, hipStream_t s, bool* used_split)
 {
     const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
@@ -1027,6 +1031,16 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         if (rcd != GRT_OK) return rcd;
         cost_src = c->d_cost_dil;
     }
+    c->order_launch = 0;
+    if (c->parts_ok && c->opt_tile_parts2_x2 > 0 && n_units == a.n_blocks * 4u) {
+        // tile kernel, camera rays, no meshes: the heaviest tiles of this frame run as 2 / 4 waves in the next one
+        *used_split = false;
+        const uint32_t cap = parts_extra_cap(n_units);
+        int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_x2,
+                                         (uint32_t)c->opt_tile_parts4_x2, s, &c->err);
+        if (rcp == GRT_OK) c->order_launch = n_units + cap;
+        return rcp;
+    }
     *used_split = split;
     return order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
                                (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
@@ -1035,6 +1049,7 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
 static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units, bool need_cost)
 {
     a.order = nullptr;
+    a.n_launch = 0;
     a.cost = nullptr;
     a.n_heavy = nullptr;
     a.heavy_role = 0;
@@ -1049,7 +1064,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_cap = 0;
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
-        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * n_units));
+        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units))));
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
     }
@@ -1067,6 +1082,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         // the very frame the order was made from (same scene, camera, options): a tile's cost does not depend on the launch
         // order, so this frame would measure the same costs and make the same order again — keep it, collect nothing
         a.order = c->d_order;
+        a.n_launch = c->order_launch;
         if (c->order_split) a.n_heavy = c->d_n_heavy;
         return GRT_OK;
     }
@@ -1082,6 +1098,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         //  there is — this frame collects costs again)
         if (c->order_valid) {
             a.order = c->d_order;
+            a.n_launch = c->order_launch;
             if (c->order_split) a.n_heavy = c->d_n_heavy;
         }
     } else if (c->opt_cold_estimate && n_units == a.n_blocks * 4u && sc->n && (a.mode == 0 || a.mode == 1)) {
@@ -1100,6 +1117,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         int rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
+        c->order_launch = 0;
         c->order_valid = true;
         c->order_split = false;
     } else {
@@ -1179,6 +1197,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         // kernels per 16x16 block (same test as launch_render)
         const uint32_t h = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
         const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
+        c->parts_ok = a.mode != 2 && !sc->n_faces && uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims);
         int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks,
                                    uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims));
         if (rcf != GRT_OK) return rcf;

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
     const uint32_t tid = threadIdx.x;
     if (tid < 128u) hist[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost[i])], 1u); // bucket 0 = heaviest
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
     __syncthreads();
     if (tid == 0u) {
         uint32_t acc = 0, bmed = 127u;
@@ -484,9 +484,87 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024u) {
         const uint32_t i = base + tid;
-        if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost[i])], 1u)] = i;
+        if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost_eff(cost[i]))], 1u)] = i;
         __syncthreads();
     }
+}
+
+// The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes): a tile's critical path —
+// one wave walking its frontier and compositing sweep after sweep — is ~0.9 ms on the 1 M scene, half the frame of one GPU and
+// all of the frame of a rank that owns an eighth of the tiles.  A tile whose cost of the previous frame (its own, not the dilated
+// one that orders the launch) exceeds thr2_x2 / 2 x the median cost runs as two waves of 4 x 8 pixels, above thr4_x2 / 2 x as
+// four of 4 x 4: half / a quarter of the rays per wave, a narrower frustum, the same pixels bit for bit.  Entry = unit |
+// part << 28 | code << 30; the parts of a tile are consecutive; everything past the last entry is kOrderPad.  When the parts
+// would not fit extra_cap the four-way class is demoted to two-way, then splitting is off for the frame (deterministic).
+__global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n,
+                                                           uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t thr2_x2, uint32_t thr4_x2)
+{
+    __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
+    __shared__ uint32_t s_t2, s_t4, s_mode, s_total;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 128u) { hist[tid] = 0u; h2[tid] = 0u; h4[tid] = 0u; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t acc = 0, bmed = 127u;
+        bool found = false;
+        for (uint32_t b = 0; b < 128u; b++) {
+            acc += hist[b];
+            if (!found && acc > n / 2u) { bmed = b; found = true; }
+        }
+        const uint32_t med = max(cost_class_floor(127u - bmed), 1u);
+        s_t2 = thr2_x2 ? (uint32_t)min((uint64_t)med * thr2_x2 >> 1, (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+        s_t4 = thr4_x2 ? (uint32_t)min((uint64_t)med * thr4_x2 >> 1, (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t t2 = s_t2, t4 = s_t4;
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
+        if (r > t4) atomicAdd(&h4[b], 1u);
+        else if (r > t2) atomicAdd(&h2[b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t n2 = 0, n4 = 0;
+        for (uint32_t b = 0; b < 128u; b++) { n2 += h2[b]; n4 += h4[b]; }
+        const uint32_t mode = (3u * n4 + n2 <= extra_cap) ? 2u : ((n4 + n2 <= extra_cap) ? 1u : 0u);
+        uint32_t acc = 0;
+        for (uint32_t b = 0; b < 128u; b++) {
+            cursor[b] = acc;
+            acc += hist[b] + (mode == 2u ? 3u * h4[b] + h2[b] : (mode == 1u ? h4[b] + h2[b] : 0u));
+        }
+        s_mode = mode;
+        s_total = acc;
+    }
+    __syncthreads();
+    const uint32_t mode = s_mode;
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + tid;
+        if (i < n) {
+            const uint32_t r = cost_eff(raw[i]);
+            uint32_t code = (r > t4) ? 2u : ((r > t2) ? 1u : 0u);
+            code = min(code, mode);
+            const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
+            const uint32_t pos = atomicAdd(&cursor[127u - cost_class(cost_eff(cost[i]))], parts);
+            for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = s_total + tid; i < n + extra_cap; i += 1024u) order[i] = kOrderPad;
+}
+
+int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
+                           uint32_t thr2_x2, uint32_t thr4_x2, hipStream_t stream, std::string* err)
+{
+    if (n == 0) return GRT_OK;
+    hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, thr2_x2, thr4_x2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("order_units_with_parts: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
 }
 
 // Under a MOVING camera a heavy tile of the previous frame is a slightly different tile of this one: every 8x8 tile
@@ -505,7 +583,7 @@ __global__ void k_cost_dilate(const uint32_t* __restrict__ cost, uint32_t* __res
             const int x = tx + dx, y = ty + dy;
             if (x < 0 || y < 0 || x >= ntx || y >= nty) continue;
             const uint32_t v = cost[(((uint32_t)y >> 1) * nbx + ((uint32_t)x >> 1)) * 4u + (((uint32_t)y & 1u) << 1) + ((uint32_t)x & 1u)];
-            m = max(m, v);
+            m = max(m, cost_eff(v));
         }
     out[u] = m;
 }

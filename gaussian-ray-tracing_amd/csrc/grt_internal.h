@@ -101,6 +101,7 @@ struct RenderArgs {
     uint32_t swizzle_chunk; // see xcd_swizzle (grt_device.h); 0 = identity
     uint32_t n_units;      // scheduling units of order[] / cost[]: n_blocks (256-thread kernels) or 4 * n_blocks (streaming: one per 8x8 tile)
     const uint32_t* order;  // cost-sorted block order from the previous frame (heaviest first) or nullptr
+    uint32_t n_launch;      // tile kernel: entries of order[] = workgroups to launch (units + the extra parts of split tiles + padding); 0 = n_units
     uint32_t* cost;         // [n_blocks] per-block cost of THIS frame (max wave iterations), zeroed before launch
     const uint32_t* n_heavy; // device count of leading blocks of `order` that run on the big-window kernel
     uint32_t heavy_role;     // 0 = every block, 1 = only ranks < *n_heavy, 2 = only ranks >= *n_heavy
@@ -159,6 +160,17 @@ constexpr int kNumCounters = 8;
 // bits of RenderArgs::err_word
 constexpr uint32_t kErrWatchdog = 1u, kErrStack = 2u, kErrStall = 4u;
 constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // give-up reasons in a tile's cost word
+// A heavy 8x8 tile may be launched as 2 waves (4 rows each) or 4 waves (4x4 pixels each): an entry of the launch order is
+// unit | part << 28 | code << 30 (code 1 = two parts, 2 = four; 0xFFFFFFFF = padding: the wave exits), and the cost word
+// such a tile leaves carries its code in bits 27-28 beside the largest step count of its parts — the feedback kernels scale
+// that back to the whole tile's (cost_eff: x 1.5 / x 2), or a tile would be split on every other frame only.
+constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
+constexpr uint32_t kCostPartShift = 27u, kCostStepsMask = 0x07FFFFFFu;
+__host__ __device__ inline uint32_t cost_eff(uint32_t c)
+{
+    const uint32_t code = (c >> kCostPartShift) & 3u, steps = c & kCostStepsMask;
+    return code ? (uint32_t)(((uint64_t)steps * (code + 2u)) >> 1) : steps;
+}
 constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
 constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
 // The stack receives the batch that overflowed (<= 64) plus up to kTileWide - 1 siblings per 8-wide level below it
@@ -195,6 +207,9 @@ inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, i
 // per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)
 int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,
                       std::string* err);
+// launch order with the heaviest tiles as 2 / 4 parts (tile kernel): n + extra_cap entries, padded with kOrderPad
+int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
+                           uint32_t thr2_x2, uint32_t thr4_x2, hipStream_t stream, std::string* err);
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
                         uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
@@ -235,6 +250,9 @@ struct grt_ctx {
     uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
+    int opt_tile_parts2_x2 = 0, opt_tile_parts4_x2 = 0; // GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2 (0 = never split a tile)
+    bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
+    uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)
     uint32_t* h_err = nullptr;    // pinned copy of it, refreshed behind every frame on the frame's stream (read after ev_tail)
     hipStream_t tail_stream = nullptr; // stream the post-frame work (next order, zeroing) was queued on

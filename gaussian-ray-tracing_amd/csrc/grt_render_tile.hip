@@ -118,11 +118,15 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 // Checking build (make EXTRA=-DGRT_TILE_CHECK, never shipped): stall_exits counts violated invariants (an event turning
 // up below the front: +1 per lane; frontier entries not conserved by a rebalance: +1000 per lane) and, when a float
 // frame is rendered, row 0 of it receives the (t, 2 id + exit, T) log of the events lane GRT_TILE_CHECK_LANE composites.
-// Experiment switch (never shipped; profiles/r04_experiments_log.md): hardware reciprocal / reciprocal square root (1 ulp) in the
-// frustum fit instead of the correctly rounded divisions and square roots.  Bit 0: the per-lane 1 / (d . axis); bit 1: the
-// plane normals; bit 2: the per-axis slab bounds.  0 = the exact arithmetic that ships.
+// Hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp) in the frustum fit instead of the correctly
+// rounded divisions and square roots (a tile re-fits its frustum every time half of its wanting lanes have finished).  Bit 0:
+// the per-lane 1 / (d . axis) — (tu, tv) move by 1.2e-7 relative, the bounds are widened by 1e-4; bit 1: the plane normals —
+// unit to 1.2e-7, against the 2e-5 slack of the plane tests; bit 2: the per-axis slab bounds — (1 - 1e-6) / max|d| within
+// 2.4e-7, still a lower bound.  Culling only: frames are bit-identical.  7 (all three) ships since round 4 (C3 -1.3 %); 0 = the
+// exact arithmetic.  This is the build that failed in round 3 — a register-allocator defect, not numerics:
+// profiles/r04_experiments_log.md, csrc/hipcc_via_asm.py.
 #ifndef GRT_FIT_APPROX
-#define GRT_FIT_APPROX 0
+#define GRT_FIT_APPROX 7
 #endif
 #if GRT_FIT_APPROX & 1
 #define GRT_FIT_RCP1(x) __builtin_amdgcn_rcpf(x)
@@ -159,7 +163,16 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #define GRT_PROBE_NOP 0
 #endif
 #endif
-#ifdef GRT_TILE_DIAG
+// Pair-statistics build (make EXTRA=-DGRT_TILE_DIAG2, never shipped; counters on; profiles/tools/diag2.py): what packing the
+// exact test into (ray, particle) pairs could save, measured before it is built.  Per wave: segments = particles fetched,
+// proxy_tests = exact tests run, rec_fetches - 2 node_visits = leaf steps (as in the diagnostic build); rays = lanes the sphere
+// pre-test lets through, summed over the exact tests; hit_evals = lanes that hit; node_visits = exact tests with a hit at all;
+// rounds = passes of 64 pairs if a leaf step's pre-test-positive pairs were packed perfectly; stall_exits = passes if two
+// consecutive survivors shared a pass whenever their pairs fit 64 lanes.
+#ifdef GRT_TILE_DIAG2
+#define GRT_TILE_DIAG
+#define GRT_D(f, n) if (COUNT) w2.f += (n);
+#elif defined(GRT_TILE_DIAG)
 #define GRT_D(f, n) if (COUNT) w.f += (n);
 #elif defined(GRT_MARKS)
 #define GRT_D(f, n) asm volatile("; GRT_MARK " #f);
@@ -352,7 +365,18 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     if (BUNDLE && unit_s >= n_in) break; // wave-uniform
     Cnt c, w;
     (void)w;
-    const uint32_t unit = (a.order && !BUNDLE) ? a.order[rank] : unit_s;
+#ifdef GRT_TILE_DIAG2
+    Cnt w2;
+#endif
+    // camera rays: an entry of the launch order may name a PART of a heavy tile (grt_internal.h: kOrderUnitMask; grt_bvh.hip:
+    // k_cost_order_parts) — the wave then traces the tile's upper / lower 4 rows, or one of its 4x4 quadrants, and the other
+    // lanes carry no ray; entries past the last one are padding
+    const uint32_t ue = (a.order && !BUNDLE) ? a.order[rank] : unit_s;
+    if (!BUNDLE && ue == kOrderPad) break; // wave-uniform
+    const uint32_t unit = BUNDLE ? ue : (ue & kOrderUnitMask);
+    // (lane = 8 row + column: bit 5 = lower half of the tile, bit 2 = right half; formed from `ue` where it is needed — at the
+    //  ray set-up and at the pixel write — so that nothing but `ue` lives across the passes)
+#define GRT_IN_PART (BUNDLE || (ue >> 30) == 0u || (((ue >> 30) == 1u ? (lane >> 5) : (((lane >> 5) << 1) | ((lane >> 2) & 1u))) == ((ue >> 28) & 3u)))
     // the heaviest tiles of the previous frame (the head of the cost-sorted order) bound the frame: they issue first
     if (!BUNDLE && a.order && a.tile_prio_div && rank < gridDim.x / a.tile_prio_div) __builtin_amdgcn_s_setprio(2);
     const uint32_t blk = unit >> 2, wave = unit & 3u;
@@ -403,6 +427,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
         if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
         else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
     }
+    have_ray = have_ray && GRT_IN_PART;
     if (COUNT && have_ray && !MESH) c.rays++;
     have_ray = have_ray && (length3(d) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
     float seg_tmax = a.p.t_max;
@@ -1087,6 +1112,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 if (leaf_step) {
                     GRT_D(fetches, 1)
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
+#ifdef GRT_TILE_DIAG2
+                    uint32_t d2_sum = 0, d2_prev = 0, d2_passes = 0;
+#endif
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
                     const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
                     while (SINGLE ? trip : (wm != 0ull)) {
@@ -1136,6 +1164,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             const uint64_t m_ = (wave_ballot(cc_ <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_)) &
                                                 (SINGLE ? wave_ballot(act_) : alivem_);
                             if (!m_) continue;
+#ifdef GRT_TILE_DIAG2
+                            if (COUNT) {
+                                const uint32_t pc_ = (uint32_t)__popcll(m_);
+                                w.rays += pc_;
+                                d2_sum += pc_;
+                                if (d2_prev && d2_prev + pc_ <= 64u) d2_prev = 0u; else { d2_passes++; d2_prev = pc_; }
+                            }
+#endif
                         }
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
@@ -1167,6 +1203,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             pa[7] = e2.w; pa[8] = e3.x; pa[9] = e3.y;
                         }
                         const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && act_;
+#ifdef GRT_TILE_DIAG2
+                        if (COUNT) { const uint64_t hm_ = wave_ballot(hit); w.hit_evals += (uint32_t)__popcll(hm_); w.node_visits += hm_ ? 1u : 0u; }
+#endif
                         const uint32_t id = __float_as_uint(r2.w);
                         const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
                         // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
@@ -1235,6 +1274,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid)
                         }
                     }
+#ifdef GRT_TILE_DIAG2
+                    if (COUNT) { w.rounds += (d2_sum + 63u) / 64u; w.stall_exits += d2_passes; }
+#endif
                     continue;
                 }
                 GRT_D(rays, 1)
@@ -1290,7 +1332,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             }
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
-        if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[unit], iters);
+        // (unit and part code are taken from the ONE scalar that lives across the passes, the order entry)
+        if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[ue & kOrderUnitMask], iters | ((ue >> 30) << kCostPartShift));
 #ifdef GRT_TILE_ACC_LDS
         if (!SINGLE) { const float4 ac_ = acc_lds[lane]; T = ac_.w; radiance = mk3(ac_.x, ac_.y, ac_.z); }
 #endif
@@ -1378,7 +1421,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                __uint_as_float((uint32_t)out_idx), __uint_as_float((uint32_t)(out_idx >> 32)));
         }
     }
-    const bool write_px = write && !cont; // queued rays write their pixel in stage 3
+    const bool write_px = write && !cont && GRT_IN_PART; // queued rays write their pixel in stage 3
     if (write_px) {
         if (a.outf) {
             a.outf[out_idx * 3] = col.x; a.outf[out_idx * 3 + 1] = col.y; a.outf[out_idx * 3 + 2] = col.z;
@@ -1389,6 +1432,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             a.out8[out_idx * 3 + 2] = quantize8(col.z);
         }
     }
+#ifdef GRT_TILE_DIAG2
+    w.segments = w2.segments; w.proxy_tests = w2.proxy_tests; w.fetches = w2.fetches;
+#endif
 #ifdef GRT_TILE_DIAG
     if (COUNT) { c = (lane == 0) ? w : Cnt(); c.fetches = w.fetches; }
 #endif
@@ -1416,6 +1462,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     } // for unit_s
 }
 
+#undef GRT_IN_PART
 #undef KS
 #undef KLAST
 #undef KPRESS
@@ -1482,7 +1529,8 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
     const bool sh = a.p.sh_degree_max > 0;
     RenderArgs b = a;
     b.heavy_role = 0;
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(a.n_blocks * 4u), dim3(kWG), 0, stream, b);
+    const uint32_t grid = (mode == 0 && a.order && a.n_launch) ? a.n_launch : a.n_blocks * 4u; // (+ the parts of split tiles, padded)
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, stream, b);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("k_render_tile launch: ") + hipGetErrorString(e);

@@ -1,6 +1,9 @@
 #include "HipGlue.h"
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <vector>
 
 #include <stdexcept>
 #include <string>
@@ -26,4 +29,37 @@ void copyPeerAsync(void* dst, int dst_device, const void* src, int src_device, s
     chk(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)stream), "hipMemcpyPeerAsync");
 }
 void copyToHostAsync(void* dst, const void* src, size_t bytes, void* stream) { chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync"); }
+
+struct Rccl { std::vector<ncclComm_t> comms; };
+static void nchk(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+Rccl* rcclInitAll(const int* devices, int n)
+{
+    Rccl* r = new Rccl();
+    r->comms.resize((size_t)n);
+    const ncclResult_t e = ncclCommInitAll(r->comms.data(), n, devices);
+    if (e != ncclSuccess) { delete r; nchk(e, "ncclCommInitAll"); }
+    return r;
+}
+void rcclGatherToRoot(Rccl* r, int rank, const void* send, size_t send_bytes, void* recv_base, const size_t* bytes_of_rank, size_t slice_bytes,
+                      void* stream)
+{
+    // grouped point-to-point: 7 peers -> 7 distinct xGMI links into rank 0 (no ring; a rank with nothing to send still takes
+    // part with a zero-byte message so that the group matches on every rank)
+    const int n = (int)r->comms.size();
+    nchk(ncclGroupStart(), "ncclGroupStart");
+    nchk(ncclSend(send, send_bytes, ncclUint8, 0, r->comms[(size_t)rank], (hipStream_t)stream), "ncclSend");
+    if (rank == 0)
+        for (int k = 0; k < n; k++)
+            nchk(ncclRecv((char*)recv_base + (size_t)k * slice_bytes, bytes_of_rank[k], ncclUint8, k, r->comms[0], (hipStream_t)stream), "ncclRecv");
+    nchk(ncclGroupEnd(), "ncclGroupEnd");
+}
+void rcclDestroy(Rccl* r)
+{
+    if (!r) return;
+    for (ncclComm_t c : r->comms) (void)ncclCommDestroy(c);
+    delete r;
+}
 }

@@ -16,4 +16,12 @@ void  copyToHostAsync(void* dst, const void* src, size_t bytes, void* stream);
 int   deviceCount();
 void  setDevice(int device);
 void  copyPeerAsync(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
+// RCCL over xGMI ("one RCCL gather to rank 0 per frame — ncclGather, rccl.h:745, or grouped ncclSend /
+// ncclRecv"): one communicator per rank of this process (ncclCommInitAll); every rank's host thread calls gatherToRoot
+// for its own rank, rank 0's call also posts the receives into the slices of its gather buffer.  Distinct devices only.
+struct Rccl;
+Rccl* rcclInitAll(const int* devices, int n);
+void  rcclGatherToRoot(Rccl* r, int rank, const void* send, size_t send_bytes, void* recv_base, const size_t* bytes_of_rank,
+                       size_t slice_bytes, void* stream);
+void  rcclDestroy(Rccl* r);
 }

@@ -3,7 +3,9 @@
 // defaults (src/main.cpp:62-66: ../data/train.ply, 1280x720), the same call sequence
 // (tracer.setSize -> initializeOptix -> camera init (src/gui.cpp:50-67) -> updateCamera -> render),
 // plus --fisheye --type --sh-degree --plane --sphere --obj --bounces --out frame.ppm|frame.png|frame.npy --bench N
-// --gpus N (tile-sharded over N GPUs of the node: one tracer and one host thread per GPU, peer copies to the first).
+// --gpus N (tile-sharded over N GPUs of the node: one tracer and one host thread per GPU; the ranks' tile buffers reach the first
+// GPU by ONE RCCL gather per frame over xGMI — grouped ncclSend / ncclRecv, --gather rccl, the default on distinct devices —
+// or by peer copies, --gather peer, the fallback when ranks share a device).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -96,10 +98,13 @@ static void usage()
     std::puts("usage: grt_render [-p|--ply scene.ply] [--width W] [--height H] [--fisheye] [--type mirror|normal|glass]\n"
               "                  [--sh-degree 0..3] [--plane] [--sphere] [--obj mesh.obj] [--bounces N]\n"
               "                  [--eye x y z] [--fov deg] [--out frame.ppm|frame.png|frame.npy] [--raw frame.rgb]\n"
-              "                  [--move dx dy dz] [--bench N] [--gpus N] [--devices d0,d1,...]\n"
+              "                  [--move dx dy dz] [--bench N] [--gpus N] [--devices d0,d1,...] [--gather rccl|peer]\n"
               "  --gpus N: the frame's 32x32 tiles are dealt round-robin to N GPUs of this node (one GaussianTracer and one host\n"
               "            thread per GPU, scene replicated), the tile buffers are copied to the first GPU over xGMI and un-permuted\n"
-              "            there.  --devices names the GPUs (default 0..N-1; a device may repeat: ranks then share it).");
+              "            there.  --devices names the GPUs (default 0..N-1; a device may repeat: ranks then share it).\n"
+              "  --gather rccl|peer: how the tile buffers reach the first GPU: one RCCL gather per frame (grouped ncclSend / ncclRecv;\n"
+              "            default when the devices are distinct; given explicitly it also sends a --gpus 1 frame through the tile\n"
+              "            path) or hipMemcpyPeerAsync (default when ranks share a device, which RCCL does not allow).");
 }
 
 int main(int argc, char** argv)
@@ -111,6 +116,7 @@ int main(int argc, char** argv)
     bool fisheye = false, plane = false, sphere = false;
     int type = MIRROR, bench = 0, gpus = 1;
     std::vector<int> devices;
+    std::string gather; // "" = auto
     float eye[3] = {0.0f, 0.0f, 3.0f}, fov = 60.0f;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -132,6 +138,7 @@ int main(int argc, char** argv)
         else if (a == "--move") { need(3); for (int k = 0; k < 3; k++) move[k] = (float)std::atof(argv[++i]); have_move = true; }
         else if (a == "--bench") { need(1); bench = std::atoi(argv[++i]); }
         else if (a == "--gpus") { need(1); gpus = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--gather") { need(1); gather = argv[++i]; if (gather != "rccl" && gather != "peer") { usage(); return 2; } }
         else if (a == "--devices") {
             need(1);
             for (const char* q = argv[++i]; *q;) { devices.push_back(std::atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
@@ -195,7 +202,16 @@ int main(int argc, char** argv)
         const size_t tile_bytes = (size_t)TILE * TILE * 3;
         std::vector<unsigned char*> mine((size_t)gpus, nullptr);
         unsigned char* gathered = nullptr;
-        if (gpus > 1) {
+        bool distinct = true;
+        for (size_t i = 0; i < devices.size(); i++) for (size_t j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
+        if (gather == "rccl" && !distinct) throw std::runtime_error("--gather rccl needs distinct devices (RCCL allows one rank per GPU)");
+        const bool use_rccl = gather == "rccl" || (gather.empty() && gpus > 1 && distinct);
+        const bool tiled = gpus > 1 || gather == "rccl"; // the N-rank path (at one rank too, when the collective is asked for)
+        hipglue::Rccl* rccl = use_rccl ? hipglue::rcclInitAll(devices.data(), gpus) : nullptr;
+        std::vector<size_t> bytes_of_rank((size_t)gpus, 0);
+        for (int k = 0; k < gpus; k++)
+            bytes_of_rank[(size_t)k] = (size_t)((n_tiles > (unsigned)k) ? (n_tiles - (unsigned)k + (unsigned)gpus - 1) / (unsigned)gpus : 0u) * tile_bytes;
+        if (tiled) {
             for (int k = 0; k < gpus; k++) {
                 hipglue::setDevice(devices[(size_t)k]);
                 mine[(size_t)k] = static_cast<unsigned char*>(hipglue::deviceAlloc(max_cnt * tile_bytes));
@@ -204,13 +220,17 @@ int main(int argc, char** argv)
             gathered = static_cast<unsigned char*>(hipglue::deviceAlloc((size_t)gpus * max_cnt * tile_bytes));
         }
         auto frame = [&] {
-            if (gpus == 1) { tracer.render(output_buffer); return; }
+            if (!tiled) { tracer.render(output_buffer); return; }
             per_rank([&](int k, GaussianTracer& t) {
-                const unsigned int cnt = (n_tiles > (unsigned)k) ? (n_tiles - (unsigned)k + (unsigned)gpus - 1) / (unsigned)gpus : 0u;
+                const unsigned int cnt = (unsigned int)(bytes_of_rank[(size_t)k] / tile_bytes);
                 t.renderTiles(mine[(size_t)k], TILE, TILE, (unsigned)k, (unsigned)gpus, cnt);
-                // the rank's compact buffer -> its slice of rank 0's gather buffer (peer copy over xGMI), behind the render
-                hipglue::copyPeerAsync(gathered + (size_t)k * max_cnt * tile_bytes, tracer.device(), mine[(size_t)k], t.device(),
-                                       (size_t)cnt * tile_bytes, t.stream);
+                // the rank's compact buffer -> its slice of rank 0's gather buffer, behind the render on the rank's stream:
+                // one RCCL gather over xGMI (every rank's thread joins the group), or a peer copy
+                if (rccl)
+                    hipglue::rcclGatherToRoot(rccl, k, mine[(size_t)k], bytes_of_rank[(size_t)k], gathered, bytes_of_rank.data(), max_cnt * tile_bytes, t.stream);
+                else
+                    hipglue::copyPeerAsync(gathered + (size_t)k * max_cnt * tile_bytes, tracer.device(), mine[(size_t)k], t.device(),
+                                           (size_t)cnt * tile_bytes, t.stream);
                 t.sync();
             });
             tracer.assembleTiles(gathered, (unsigned)gpus, max_cnt, TILE, TILE, output_buffer);
@@ -229,12 +249,13 @@ int main(int argc, char** argv)
             }
             std::sort(ms.begin(), ms.end());
             const double med = ms[ms.size() / 2];
-            std::printf("frames %d  median %.3f ms/frame  kernel %.3f ms%s  %.1f Mrays/s (primary)  gpus %d\n", bench, med, kms / bench,
-                        gpus > 1 ? " (rank 0)" : "", (double)width * height / med / 1e3, gpus);
+            std::printf("frames %d  median %.3f ms/frame  kernel %.3f ms%s  %.1f Mrays/s (primary)  gpus %d  gather %s\n", bench, med, kms / bench,
+                        gpus > 1 ? " (rank 0)" : "", (double)width * height / med / 1e3, gpus, !tiled ? "none" : (rccl ? "rccl" : "peer"));
         }
         for (int k = 0; k < gpus; k++) { if (mine[(size_t)k]) { hipglue::setDevice(devices[(size_t)k]); hipglue::deviceFree(mine[(size_t)k]); } }
         hipglue::setDevice(tracer.device());
         hipglue::deviceFree(gathered);
+        hipglue::rcclDestroy(rccl);
         if (!raw_out.empty()) { // the buffer as the renderer wrote it (row 0 first), from the pinned mirror render() filled
             std::ofstream f(raw_out, std::ios::binary);
             f.write(reinterpret_cast<const char*>(output_buffer.getHostPointer()), (std::streamsize)((size_t)width * height * 3));

@@ -182,7 +182,12 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          and sets the sticky error word */,
        GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
                                          segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
-                                         finishes it (default 128).  Same image for every value */ };
+                                         finishes it (default 128).  Same image for every value */,
+       GRT_OPT_TILE_PARTS2_X2 = 26    /* tile kernel, camera rays without meshes: an 8x8 tile whose cost in the previous frame exceeded
+                                         value/2 x the median tile cost is launched as TWO waves of 4x8 pixels (half the rays each, a
+                                         narrower frustum): the frame's critical path is its heaviest tile.  0 = never.  Pixels never
+                                         depend on it */,
+       GRT_OPT_TILE_PARTS4_X2 = 27    /* ... above value/2 x the median: FOUR waves of 4x4 pixels.  0 = never */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

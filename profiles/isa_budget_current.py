@@ -32,8 +32,15 @@ def demangle(names):
 
 
 def instr_stats(lines):
-    c = {"instructions": 0, "valu": 0, "salu": 0, "spill_instructions": 0, "lane_moves": 0, "lds": 0, "vmem": 0, "smem": 0}
+    """(the assembly printer says for every machine basic block which loop it is in: `.LBBx_y: ; in Loop: Header=… Depth=N`)"""
+    c = {"instructions": 0, "valu": 0, "salu": 0, "spill_instructions": 0, "spill_instructions_in_loops": 0, "lane_moves": 0,
+         "lane_moves_in_loops": 0, "lds": 0, "vmem": 0, "smem": 0}
+    depth = 0
     for l in lines:
+        m = re.match(r"^\.LBB\d+_\d+:(.*)$", l)
+        if m:
+            d = re.search(r"Depth=(\d+)", m.group(1))
+            depth = int(d.group(1)) if d else 0
         t = l.strip()
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
             continue
@@ -41,6 +48,7 @@ def instr_stats(lines):
         c["instructions"] += 1
         if op.startswith(("v_readlane", "v_writelane")):
             c["lane_moves"] += 1
+            c["lane_moves_in_loops"] += 1 if depth else 0
         elif op.startswith("v_"):
             c["valu"] += 1
         elif op.startswith(("s_load", "s_buffer_load")):
@@ -49,6 +57,7 @@ def instr_stats(lines):
             c["salu"] += 1
         elif op.startswith("scratch_"):
             c["spill_instructions"] += 1
+            c["spill_instructions_in_loops"] += 1 if depth else 0
         elif op.startswith("ds_"):
             c["lds"] += 1
         elif op.startswith(("global_", "buffer_", "flat_")):

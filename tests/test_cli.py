@@ -176,3 +176,25 @@ def test_cli_gpus_n_tile_sharded_frame_equals_the_one_gpu_frame(tmp_path):
     assert "gpus 3" in r.stdout
     a, b = np.load(one), np.load(three)
     assert a.shape == (136, 200, 3) and a.any() and (a == b).all()
+
+
+@pytest.mark.gpu
+def test_cli_rccl_gather_at_one_rank_equals_the_one_launch_frame(tmp_path):
+    """--gather rccl (ncclGather, rccl.h:745, or grouped ncclSend / ncclRecv): the C++ host
+    path of the N-rank frame — ncclCommInitAll, every rank's thread posting its send, rank 0 the receives into the slices of
+    ONE [N][count][32][32][3] buffer, un-permute — executed on the hardware there is: one rank, so the frame goes
+    render_tiles -> RCCL send / recv to itself -> assemble and must equal the one-launch frame byte for byte.  Asking for
+    RCCL with ranks that share a device is refused (RCCL allows one rank per GPU: the peer-copy fallback is for that)."""
+    ply, acts = _scene(tmp_path)
+    one, coll = str(tmp_path / "one.npy"), str(tmp_path / "coll.npy")
+    common = [CLI, "-p", ply, "--width", "200", "--height", "136", "--type", "mirror", "--sphere", "--bounces", "3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(common + ["--out", one], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(common + ["--out", coll, "--gpus", "1", "--gather", "rccl", "--bench", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "gather rccl" in r.stdout
+    a, b = np.load(one), np.load(coll)
+    assert a.shape == (136, 200, 3) and a.any() and (a == b).all()
+    r = subprocess.run(common + ["--gpus", "2", "--devices", "0,0", "--gather", "rccl"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "distinct devices" in r.stderr

@@ -66,6 +66,56 @@ def test_options_do_not_change_pixels():
     tr.close()
 
 
+def test_heavy_tiles_as_part_waves_give_the_same_frame():
+    """GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2: an 8x8 tile that was heavy in the previous frame runs as two waves of 4x8 pixels or
+    four of 4x4.  Pure scheduling: full frames, windows and rank tile lists must not change by a byte, whatever the
+    thresholds (so low here that nearly every tile is split; four-way only; two-way only; more parts than the launch has room
+    for, which demotes them), frame after frame (a split tile's cost word is scaled back so that it stays split), and the
+    per-ray counters must be those of whole tiles."""
+    import torch
+    acts, p, sc, op, _ = make_scene(31, 30000, 200, 136, scale_boost=0.45)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    ref8, reff = tr.render(p, want_f32=True)
+    ref8, reff = ref8.clone(), reff.clone()
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    tr.render(p)
+    c0 = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    w8 = torch.zeros_like(ref8)
+    for v2, v4 in ((1, 0), (1, 1), (0, 1), (3, 6), (2, 5), (8, 24)):
+        tr.set_option(grt.OPT_TILE_PARTS2_X2, v2)
+        tr.set_option(grt.OPT_TILE_PARTS4_X2, v4)
+        for it in range(4):
+            a8, af = tr.render(p, want_f32=True)
+            assert (a8 == ref8).all() and (af == reff).all(), (v2, v4, it)
+        tr.set_option(grt.OPT_COUNTERS, 1)
+        tr.render(p)
+        c1 = tr.counters()
+        tr.set_option(grt.OPT_COUNTERS, 0)
+        for k in ("rays", "segments", "hit_evals"):  # (passes may differ: which lane overflows its window depends on the wave)
+            assert c1[k] == c0[k], (k, v2, v4)
+        assert c1["stall_exits"] == 0
+        for it in range(3):  # a window (its own launch geometry, own costs)
+            w8.zero_()
+            tr.render(p, window=(24, 16, 170, 120), out_u8=w8)
+            assert (w8[16:120, 24:170] == ref8[16:120, 24:170]).all(), (v2, v4, it)
+        # a rank's tile list: 32x32 tiles 1, 3, 5, ...
+        tx, ty = (200 + 31) // 32, (136 + 31) // 32
+        cnt = (tx * ty) // 2
+        buf = torch.zeros((cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+        for it in range(3):
+            tr.render_tiles(p, 32, 32, 1, 2, cnt, out_u8=buf)
+            tr.check()
+            for j in range(cnt):
+                t = 1 + 2 * j
+                x0, y0 = (t % tx) * 32, (t // tx) * 32
+                h, w = min(32, 136 - y0), min(32, 200 - x0)
+                assert (buf[j, :h, :w] == ref8[y0:y0 + h, x0:x0 + w]).all(), (v2, v4, it, j)
+    tr.check()
+    tr.close(); sc.close()
+
+
 def test_split_launch_with_mesh_and_tiles():
     """Big-window split launch (GRT_OPT_FEEDBACK = 5) through the wavefront pipeline and the tile entry point."""
     import torch

@@ -184,9 +184,10 @@ def test_isa_budget_of_the_render_kernels():
         else:          # 4 waves per SIMD, 16 per CU: <= 128 VGPRs and <= 9984 B of LDS (64 KB / 16 x 2.5: 160 KB per CU)
             assert k["vgprs"] <= 128 and k["lds_bytes"] <= 9984, (name, k)
     c3 = b["grt::k_render_tile<false, false, false, 0, false>"]
-    # the headline kernel: its handful of spill instructions sit in cold blocks (window-overflow bag, rebalance); more than
-    # this means the allocator gave up somewhere new — look before shipping (profiles/tools/movcount.sh shows where)
-    assert c3["spill_instructions"] <= 8 and c3["scratch_bytes"] <= 32, c3
-    assert c3["instructions"] <= 5600, c3
-    c5 = b["grt::k_render_tile<false, false, false, 0, true>"]
-    assert c5["spill_instructions"] <= 16, c5
+    # the headline kernel: NO spill instruction inside any loop (what it spills is saved before the passes and reloaded for the
+    # pixel write), a bounded number outside, bounded SGPR spill traffic (v_readlane / v_writelane) — more than this means the
+    # allocator gave up somewhere new: look before shipping (profiles/tools/movcount.sh shows where)
+    assert c3["spill_instructions_in_loops"] == 0 and c3["spill_instructions"] <= 12 and c3["scratch_bytes"] <= 32, c3
+    assert c3["lane_moves"] <= 200 and c3["instructions"] <= 5200, c3
+    c5 = b["grt::k_render_tile<false, false, false, 0, true>"]  # the same with pieces (needle / sheet scenes)
+    assert c5["spill_instructions_in_loops"] <= 2 and c5["spill_instructions"] <= 16, c5  # (two in its piece-ownership block)
