@@ -110,7 +110,12 @@ __device__ __forceinline__ void slab_project(f3 v, float a[10])
 
 // exact proxy test; same operation sequence as oracle/grt_oracle.c:proxy_slabs
 // a[] = slab_project(o_g), formed by the caller (per lane, or once per eye and particle: k_eye_records)
-__device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float s, float& t_entry, float& t_exit)
+// EARLY > 0 (wave-cooperative callers, experiment GRT_TILE_EARLY_OUT): after slab EARLY the wave asks whether ANY lane of
+// `lanes` can still hit — entry <= exit so far, as the cross product nn fd <= fn nd with a 1e-5 relative slack (the entry bound
+// only grows and the exit bound only shrinks from here on, so a lane that is out by more than the slack stays out) — and
+// returns false for all of them when none can: the result is what the full test returns, six slabs earlier.
+template <int EARLY = 0>
+__device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float s, float& t_entry, float& t_exit, bool lanes = true)
 {
     float b[10];
     slab_project(d_g, b);
@@ -118,6 +123,13 @@ __device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float
     float nn = 0.0f, nd = 0.0f, fn = 0.0f, fd = 0.0f;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
+        if (EARLY > 0 && i == EARLY) {
+            const float l_ = nn * fd, r_ = fn * nd;
+            if (__builtin_amdgcn_ballot_w64(lanes && !(l_ > r_ + 1e-5f * (fabsf(l_) + fabsf(r_)) + 1e-37f)) == 0ull) {
+                t_entry = 1.0f; t_exit = 0.0f;
+                return false;
+            }
+        }
         const float h = (i >= 4 && i <= 7) ? s3 : s;
         // a with the sign of b folded in: the sign BIT of b (so b = -0 counts as negative; its slab then sits at -+1e30 times
         // something on either reading and bounds nothing), two VALU operations instead of a compare, a move and a select

@@ -250,7 +250,7 @@ struct grt_ctx {
     uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
-    int opt_tile_parts2_x2 = 0, opt_tile_parts4_x2 = 0; // GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2 (0 = never split a tile)
+    int opt_tile_parts2_x2 = 8, opt_tile_parts4_x2 = 16; // GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2 (0 = never split a tile)
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)

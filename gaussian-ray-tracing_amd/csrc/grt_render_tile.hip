@@ -1202,7 +1202,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             pa[0] = e1.x; pa[1] = e1.y; pa[2] = e1.z; pa[3] = e1.w; pa[4] = e2.x; pa[5] = e2.y; pa[6] = e2.z;
                             pa[7] = e2.w; pa[8] = e3.x; pa[9] = e3.y;
                         }
+#ifdef GRT_TILE_EARLY_OUT
+                        const bool hit = proxy_slabs_pre<SINGLE ? 0 : GRT_TILE_EARLY_OUT>(pa, d_g, r0.w, te, tx, act_) && act_;
+#else
                         const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && act_;
+#endif
 #ifdef GRT_TILE_DIAG2
                         if (COUNT) { const uint64_t hm_ = wave_ballot(hit); w.hit_evals += (uint32_t)__popcll(hm_); w.node_visits += hm_ ? 1u : 0u; }
 #endif

@@ -5,5 +5,7 @@
 #define GRT_TILE_SINGLE_TU 1
 #define GRT_TILE_KS 8
 #define GRT_TILE_WAVES2 3
+#ifndef GRT_TILE_GRID2
 #define GRT_TILE_GRID2 2816u
+#endif
 #include "grt_render_tile.hip"

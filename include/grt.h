@@ -185,9 +185,9 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          finishes it (default 128).  Same image for every value */,
        GRT_OPT_TILE_PARTS2_X2 = 26    /* tile kernel, camera rays without meshes: an 8x8 tile whose cost in the previous frame exceeded
                                          value/2 x the median tile cost is launched as TWO waves of 4x8 pixels (half the rays each, a
-                                         narrower frustum): the frame's critical path is its heaviest tile.  0 = never.  Pixels never
-                                         depend on it */,
-       GRT_OPT_TILE_PARTS4_X2 = 27    /* ... above value/2 x the median: FOUR waves of 4x4 pixels.  0 = never */ };
+                                         narrower frustum): the frame's critical path is its heaviest tile.  Default 8 (4 x the median);
+                                         0 = never.  Pixels never depend on it */,
+       GRT_OPT_TILE_PARTS4_X2 = 27    /* ... above value/2 x the median: FOUR waves of 4x4 pixels.  Default 16; 0 = never */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

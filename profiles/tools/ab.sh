@@ -1,10 +1,10 @@
 #!/bin/bash
 # profiles/tools/ab.sh <workload> <steps> label...  : kernel ms of each variant library (run on the GPU box from the repo root)
 W=$1; S=$2; shift; shift
-mkdir -p gpurun_out/r3
+mkdir -p gpurun_out/r4
 for rep in 1 2; do
 for L in "$@"; do
-  GRT_LIB=$PWD/gaussian-ray-tracing_amd/libgrt_hip_$L.so python bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-extra-legs 2> gpurun_out/r3/ab_$L.err | python -c "
+  GRT_LIB=$PWD/gaussian-ray-tracing_amd/libgrt_hip_$L.so python bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-extra-legs 2> gpurun_out/r4/ab_$L.err | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
