@@ -523,6 +523,24 @@ def cpu_baseline(acts, p, mesh, W, H):
     except Exception:
         pass
     nproc = os.cpu_count() or cores  # all host cores the process may run on, nproc printed beside them
+    affinity = cores
+    # ... of which the container may only USE its CPU quota at a time (cgroup v2 cpu.max / v1 cfs quota): the GPU box shows 256
+    # logical cores to a pod whose share is 16, and 256 oracle threads on 16 cores' worth of time run at half the speed of 16
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(round(q / per)))
+        except Exception:
+            pass
+    if quota:
+        cores = min(cores, quota)
     sc = O.Scene(acts_to_particles(acts))
     if mesh is not None:
         sc.set_mesh(*mesh)
@@ -532,7 +550,8 @@ def cpu_baseline(acts, p, mesh, W, H):
     _, _, c = sc.render(to_oracle_params(p), window=win, threads=cores, want_u8=True, want_f32=False)
     dt = time.perf_counter() - t0
     sc.close()
-    return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "nproc": nproc, "threads": cores, "kind": "port",
+    return {"value": round(c["segments"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "nproc": nproc, "affinity_cores": affinity,
+            "cgroup_cpu_quota_cores": quota, "threads": cores, "kind": "port",
             "sample": f"{'whole' if (cw, ch) == (W, H) else 'centred'} {cw}x{ch} window of the same frame ({c['segments']} rays, {dt:.1f} s); "
                       f"full-frame estimate {W * H / (c['segments'] / dt) * 1e3:.0f} ms/frame",
             "hit_evals_per_ray": round(c["hit_evals"] / max(c["segments"], 1), 2)}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the profiles this directory holds (run on the GPU box from the repo root):
-#   profiles/collect.sh <tag> [workload] [quick]      e.g.  profiles/collect.sh r03        (C3, everything)
+#   profiles/collect.sh <tag> [workload] [quick]      e.g.  profiles/collect.sh r04        (C3, everything)
 #                                                           profiles/collect.sh r03 C4 quick
 # 1. rocprofv3 --kernel-trace --stats of the bench command without its untimed extra legs (cold / orbit frames, the
 #    pipelined loop: their overlapping launches would pollute the per-kernel averages)
