@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstring>
 #include <string>
@@ -603,8 +605,9 @@ int grt_set_option(grt_ctx* c, int option, int value)
     }
     else if (option == GRT_OPT_MAX_ITERS) { c->opt_max_iters = std::max(0, value); }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
-    else if (option == GRT_OPT_TILE_PARTS2_X2) { c->opt_tile_parts2_x2 = std::min(1 << 20, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
-    else if (option == GRT_OPT_TILE_PARTS4_X2) { c->opt_tile_parts4_x2 = std::min(1 << 20, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_TILE_PARTS2_PCT) { c->opt_tile_parts2_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_TILE_PARTS4_PCT) { c->opt_tile_parts4_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
     else if (option == GRT_OPT_LEAF_MAX) {
@@ -1032,12 +1035,12 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         cost_src = c->d_cost_dil;
     }
     c->order_launch = 0;
-    if (c->parts_ok && c->opt_tile_parts2_x2 > 0 && n_units == a.n_blocks * 4u) {
+    if (c->parts_ok && (c->opt_tile_parts2_pct > 0 || c->opt_tile_parts4_pct > 0) && n_units == a.n_blocks * 4u) {
         // tile kernel, camera rays, no meshes: the heaviest tiles of this frame run as 2 / 4 waves in the next one
         *used_split = false;
         const uint32_t cap = parts_extra_cap(n_units);
-        int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_x2,
-                                         (uint32_t)c->opt_tile_parts4_x2, s, &c->err);
+        int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
+                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, s, &c->err);
         if (rcp == GRT_OK) c->order_launch = n_units + cap;
         return rcp;
     }
@@ -1295,6 +1298,12 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         if (!c->ovf_zeroed) CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
         c->ovf_zeroed = false;
         a.ovf_pool = c->d_ovf; a.ovf_next = c->d_ovf_next; a.ovf_chunks = c->ovf_chunks;
+    }
+    {
+        static const bool dbg = getenv("GRT_DEBUG_LAUNCH") != nullptr; // one line per frame on stderr: what the launch is made of
+        if (dbg)
+            fprintf(stderr, "grt launch: ctx %p mode %u units %u order %s entries %u cost %s parts_ok %d cost_valid %d order_ready %d\n", (void*)c, a.mode,
+                    a.n_units, a.order ? "yes" : "no", a.n_launch, a.cost ? "collect" : "-", (int)c->parts_ok, (int)c->cost_valid, (int)c->order_ready);
     }
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));

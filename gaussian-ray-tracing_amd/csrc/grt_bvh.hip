@@ -489,33 +489,46 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
     }
 }
 
-// The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes): a tile's critical path —
-// one wave walking its frontier and compositing sweep after sweep — is ~0.9 ms on the 1 M scene, half the frame of one GPU and
-// all of the frame of a rank that owns an eighth of the tiles.  A tile whose cost of the previous frame (its own, not the dilated
-// one that orders the launch) exceeds thr2_x2 / 2 x the median cost runs as two waves of 4 x 8 pixels, above thr4_x2 / 2 x as
-// four of 4 x 4: half / a quarter of the rays per wave, a narrower frustum, the same pixels bit for bit.  Entry = unit |
-// part << 28 | code << 30; the parts of a tile are consecutive; everything past the last entry is kOrderPad.  When the parts
-// would not fit extra_cap the four-way class is demoted to two-way, then splitting is off for the frame (deterministic).
+// The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes).  A frame takes at least
+// max(L, W / R): L the longest tile (one wave walking its frontier and compositing sweep after sweep: ~0.9 ms on the 1 M scene, half
+// the frame of one GPU and ALL of the frame of a rank that owns an eighth of the tiles), W the launch's total work, R the resident
+// waves.  Splitting a tile into four waves of 4 x 4 pixels costs ~3 x its work and takes its latency to ~0.8 (a proxy covers half a
+// tile: a quadrant's frustum still meets most of them), so it pays for the few tiles that ARE the frame and for no others: a tile
+// whose cost in the previous frame (its own, not the dilated one that orders the launch) exceeds pct4 % of the heaviest tile's AND
+// pct_load % of W / R runs as four waves (pct2: as two waves of 4 x 8 pixels; off by default — half a tile takes as long as the
+// whole).  With a frame that is bound by its total work (1080p on one GPU, 4K) nothing is split.  Entry = unit | part << 28 |
+// code << 30; the parts of a tile are consecutive; everything past the last entry is kOrderPad.  The launch has room for extra_cap
+// entries beyond one per tile: they go to the heaviest cost classes first.
 __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n,
-                                                           uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t thr2_x2, uint32_t thr4_x2)
+                                                           uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t pct2, uint32_t pct4,
+                                                           uint32_t pct_load, uint32_t resident_waves)
 {
     __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
-    __shared__ uint32_t s_t2, s_t4, s_mode, s_total;
+    __shared__ uint8_t ok4[128], ok2[128]; // the launch has room for this cost class's four-way / two-way parts
+    __shared__ uint32_t s_t2, s_t4, s_total, s_max;
+    __shared__ unsigned long long s_sum;
     const uint32_t tid = threadIdx.x;
     if (tid < 128u) { hist[tid] = 0u; h2[tid] = 0u; h4[tid] = 0u; }
+    if (tid == 0u) { s_max = 0u; s_sum = 0ull; }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
+    {
+        uint32_t mx = 0;
+        unsigned long long sm = 0;
+        for (uint32_t i = tid; i < n; i += 1024u) {
+            atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
+            const uint32_t r = cost_eff(raw[i]);
+            mx = max(mx, r);
+            sm += r;
+        }
+        for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sm += __shfl_xor(sm, off); }
+        if ((tid & 63u) == 0u) { atomicMax(&s_max, mx); atomicAdd(&s_sum, sm); }
+    }
     __syncthreads();
     if (tid == 0u) {
-        uint32_t acc = 0, bmed = 127u;
-        bool found = false;
-        for (uint32_t b = 0; b < 128u; b++) {
-            acc += hist[b];
-            if (!found && acc > n / 2u) { bmed = b; found = true; }
-        }
-        const uint32_t med = max(cost_class_floor(127u - bmed), 1u);
-        s_t2 = thr2_x2 ? (uint32_t)min((uint64_t)med * thr2_x2 >> 1, (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
-        s_t4 = thr4_x2 ? (uint32_t)min((uint64_t)med * thr4_x2 >> 1, (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+        const uint64_t lmax = s_max, load = s_sum / max(resident_waves, 1u); // the longest tile; the work per resident wave
+        const uint64_t floor_ = load * pct_load / 100u;
+        s_t4 = pct4 ? (uint32_t)min(max(lmax * pct4 / 100u, floor_), (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+        s_t2 = pct2 ? (uint32_t)min(max(lmax * pct2 / 100u, floor_), (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
     }
     __syncthreads();
     const uint32_t t2 = s_t2, t4 = s_t4;
@@ -526,27 +539,35 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
     }
     __syncthreads();
     if (tid == 0u) {
-        uint32_t n2 = 0, n4 = 0;
-        for (uint32_t b = 0; b < 128u; b++) { n2 += h2[b]; n4 += h4[b]; }
-        const uint32_t mode = (3u * n4 + n2 <= extra_cap) ? 2u : ((n4 + n2 <= extra_cap) ? 1u : 0u);
+        // room for extra_cap entries beyond one per tile: handed out heaviest class first — four-way parts, then two-way ones
+        // (a class that no longer fits four-way is tried two-way) — so that the tiles that bound the frame keep their parts
+        // whatever the lighter ones would like (deterministic: same costs, same order)
+        uint32_t extras = 0;
+        for (uint32_t b = 0; b < 128u; b++) {
+            const uint32_t e4 = 3u * h4[b];
+            ok4[b] = (e4 != 0u && extras + e4 <= extra_cap) ? 1 : 0;
+            if (ok4[b]) extras += e4;
+        }
+        for (uint32_t b = 0; b < 128u; b++) {
+            const uint32_t e2 = h2[b] + (ok4[b] ? 0u : h4[b]);
+            ok2[b] = (e2 != 0u && extras + e2 <= extra_cap) ? 1 : 0;
+            if (ok2[b]) extras += e2;
+        }
         uint32_t acc = 0;
         for (uint32_t b = 0; b < 128u; b++) {
             cursor[b] = acc;
-            acc += hist[b] + (mode == 2u ? 3u * h4[b] + h2[b] : (mode == 1u ? h4[b] + h2[b] : 0u));
+            acc += hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + (ok4[b] ? 0u : h4[b]) : 0u);
         }
-        s_mode = mode;
         s_total = acc;
     }
     __syncthreads();
-    const uint32_t mode = s_mode;
     for (uint32_t base = 0; base < n; base += 1024u) {
         const uint32_t i = base + tid;
         if (i < n) {
-            const uint32_t r = cost_eff(raw[i]);
-            uint32_t code = (r > t4) ? 2u : ((r > t2) ? 1u : 0u);
-            code = min(code, mode);
+            const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
+            const uint32_t code = (r > t4 && ok4[b]) ? 2u : ((r > t2 && ok2[b]) ? 1u : 0u);
             const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
-            const uint32_t pos = atomicAdd(&cursor[127u - cost_class(cost_eff(cost[i]))], parts);
+            const uint32_t pos = atomicAdd(&cursor[b], parts);
             for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
         }
         __syncthreads();
@@ -555,10 +576,11 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
 }
 
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t thr2_x2, uint32_t thr4_x2, hipStream_t stream, std::string* err)
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
-    hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, thr2_x2, thr4_x2);
+    hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, pct2, pct4, pct_load,
+                       resident_waves);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("order_units_with_parts: ") + hipGetErrorString(e);

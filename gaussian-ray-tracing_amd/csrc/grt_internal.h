@@ -163,13 +163,16 @@ constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // 
 // A heavy 8x8 tile may be launched as 2 waves (4 rows each) or 4 waves (4x4 pixels each): an entry of the launch order is
 // unit | part << 28 | code << 30 (code 1 = two parts, 2 = four; 0xFFFFFFFF = padding: the wave exits), and the cost word
 // such a tile leaves carries its code in bits 27-28 beside the largest step count of its parts — the feedback kernels scale
-// that back to the whole tile's (cost_eff: x 1.5 / x 2), or a tile would be split on every other frame only.
+// that back to the whole tile's (cost_eff: x 9/8 for halves, x 10/8 for quarters — measured: a quarter of the heaviest tile
+// of the 1 M scene takes 0.79 of the whole tile's time, a half all of it), or a tile would be split on every other frame only.
+// (A larger factor inflates the split tiles' costs frame over frame until their parts no longer fit the launch.)
 constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
+constexpr uint32_t kTileResidentWaves = 256u * 16u; // MI355X: 256 CUs x 16 waves of the camera-ray kernel (128 VGPRs, < 10 KB of LDS)
 constexpr uint32_t kCostPartShift = 27u, kCostStepsMask = 0x07FFFFFFu;
 __host__ __device__ inline uint32_t cost_eff(uint32_t c)
 {
     const uint32_t code = (c >> kCostPartShift) & 3u, steps = c & kCostStepsMask;
-    return code ? (uint32_t)(((uint64_t)steps * (code + 2u)) >> 1) : steps;
+    return code ? (uint32_t)(((uint64_t)steps * (8u + code)) >> 3) : steps;
 }
 constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
 constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
@@ -209,7 +212,7 @@ int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uin
                       std::string* err);
 // launch order with the heaviest tiles as 2 / 4 parts (tile kernel): n + extra_cap entries, padded with kOrderPad
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t thr2_x2, uint32_t thr4_x2, hipStream_t stream, std::string* err);
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, hipStream_t stream, std::string* err);
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
                         uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
@@ -250,7 +253,7 @@ struct grt_ctx {
     uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
-    int opt_tile_parts2_x2 = 8, opt_tile_parts4_x2 = 16; // GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2 (0 = never split a tile)
+    int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)

@@ -316,6 +316,79 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
     }
 }
 
+// One surviving particle's events into the lanes' windows (lanes = rays): keys of the entry / exit events inside the lane's
+// interval, piece ownership, the response (computed only when some lane inserts), window overflow into the lane's bag, sorted
+// insert.  A macro because two loops share it: the exact test with lanes = rays (every mode) and, in the GRT_TILE_PAIRS
+// experiment, the insert phase behind a pass over (ray, particle) pairs.  (> last_key, not just > pass_lo, with pieces: a particle
+// that entered the tree as several pieces is met once per piece the tile crosses, with the same keys; float compares first: te / tx
+// may be negative or NaN, the unsigned key compares assume t > 0; alpha does not depend on the hit distance, shaders/tracer.cuh:
+// 354-357; window full: the largest pending key leaves — into the lane's bag in global memory, or for good: the lane is then lossy
+// beyond it.)
+#ifdef GRT_TILE_CHECK
+#define GRT_TILE_CHECK_FRONT(INS, K) if ((INS) && key_t(K) < F) c.stall_exits++; /* finality violated: an event below the front turned up late */
+#else
+#define GRT_TILE_CHECK_FRONT(INS, K)
+#endif
+#define GRT_TILE_INSERT(TE_, TX_, HIT_, ID_, ALPHA_, S_, OG_, DG_, CELLB_)                                        \
+                        const uint32_t id = (ID_); \
+                        const uint64_t ke = mk_skey((TE_), id, 0), kx = mk_skey((TX_), id, 1); \
+                        const uint64_t seen_ = PIECES ? last_key : pass_lo; \
+                        bool in_e = (HIT_) && ((TE_) >= t_lo) && ((TE_) < t_hi) && (ke > seen_); \
+                        bool in_x = (HIT_) && ((TX_) >= t_lo) && ((TX_) < t_hi) && (kx > seen_); \
+                        const uint32_t cellb = PIECES ? (CELLB_) : 0u; \
+                        if (PIECES && cellb) { \
+                            const bool own_ = piece_owns(cellb, (S_), (OG_), (DG_), in_e ? (TE_) : (TX_)); \
+                            in_e = in_e && own_; \
+                            in_x = in_x && own_; \
+                        } \
+                        const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); \
+                        const bool ins = (k_first != kKeyInvalid) && (k_first < lost); \
+                        GRT_TILE_CHECK_FRONT(ins, k_first) \
+                        if (wave_any(ins)) { \
+                            const float alpha = (ALPHA_); \
+                            const float other = (in_e && in_x) ? (TX_) : INFINITY; \
+                            const bool full = KLAST != kKeyInvalid; \
+                            const bool take = ins && (!full || k_first < KLAST); \
+                            const bool drop = ins && full; \
+                            const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask); \
+                            if (wave_any(drop)) { \
+                                if (!SINGLE && chunk == kNoRoot) { \
+                                    uint32_t ch = 0; \
+                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u); \
+                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch); \
+                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); \
+                                } \
+                                const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask); \
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost); \
+                                if (to_bag) { \
+                                    const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha; \
+                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] = \
+                                        make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a); \
+                                    nb++; \
+                                    bagmin = (dk < bagmin) ? dk : bagmin; \
+                                } \
+                                const bool gone = drop && !to_bag; \
+                                lost = (gone && (dk < lost)) ? dk : lost; \
+                                if (SINGLE) lost = wave_umin64(lost); \
+                                else bags = true; \
+                                if (wave_any(gone)) lim_dirty = true; \
+                            } \
+                            KLAST = (take && full) ? kKeyInvalid : KLAST; \
+                            pmask = take ? (pmask | (1u << cell)) : pmask; \
+                            if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; } \
+                            if (SINGLE && take) { \
+                                f3 L; \
+                                if (!SH) { \
+                                    const float4 cc = a.color0[id]; \
+                                    L = mk3(cc.x, cc.y, cc.z); \
+                                } else { \
+                                    L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max); \
+                                } \
+                                PL_COL(cell, 0) = L.x; PL_COL(cell, 1) = L.y; PL_COL(cell, 2) = L.z; \
+                            } \
+                            SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid) \
+                        }
+
 // BUNDLE = true (stage 3 of the mesh wavefront pipeline): the wave's 64 rays are one chunk of the continuation queue —
 // the rays of one 8x8 tile after their bounce, each with its own origin.  The frustum planes get offsets (each plane is
 // pushed out to the outermost origin), the distance bounds are taken about the first ray's origin and loosened by the
@@ -341,6 +414,15 @@ template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
 __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT_TILE_WAVES1 : (MODE == 0 && !MESH ? GRT_TILE_WAVES0 : GRT_TILE_WAVES))) void k_render_tile(const RenderArgs a)
 {
     constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
+    // EXPERIMENT (-DGRT_TILE_PAIRS, never shipped; profiles/r04_experiments_log.md item 4): the exact test of camera rays on compacted
+    // (ray, particle) pairs — a leaf step's survivors are pre-tested as ever (lanes = rays, scalar operands), the lanes the pre-test
+    // lets through become a pair list, <= 4 survivors / <= 64 pairs at a time are slab-tested with lanes = PAIRS (the ray's direction
+    // by ds_bpermute, the two records from an LDS copy), the results go back through LDS and the inserts run with lanes = rays again.
+#ifdef GRT_TILE_PAIRS
+    constexpr bool PAIRS = (MODE == 0) && !PIECES;
+#else
+    constexpr bool PAIRS = false;
+#endif
     const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
     const uint32_t n_in = BUNDLE ? (SINGLE ? *a.hcount : *a.qcount_in) : 0u; // chunks of the queue / rays of the heavy list
     const uint32_t lane = threadIdx.x;
@@ -350,6 +432,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #ifdef GRT_TILE_ACC_LDS
     __shared__ float4 acc_lds[SINGLE ? 1 : kWG]; // EXPERIMENT: (radiance, T) of every lane live here between compositing steps
 #endif
+    __shared__ __attribute__((aligned(16))) float pr_stg[PAIRS ? 4 * 32 : 4]; // PAIRS: record (16 dwords) + eye record (16 dwords) of <= 4 staged survivors (read as float4)
+    __shared__ uint32_t pr_list[PAIRS ? 64 : 1];  // PAIRS: pair -> ray lane | staging slot << 6
+    __shared__ float pr_res[PAIRS ? 3 * 64 : 1];  // PAIRS: entry t (+inf: no hit), exit t, alpha of every pair
+    __shared__ uint2 pr_mask[PAIRS ? 4 : 1];      // PAIRS: the staged survivors' pre-test lane masks
+    (void)pr_stg; (void)pr_list; (void)pr_res; (void)pr_mask;
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
@@ -1117,6 +1204,112 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #endif
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
                     const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
+                    if (PAIRS) {
+                        uint32_t nsl = 0, npr = 0; // survivors staged, pairs listed (wave-uniform)
+                        while (true) {
+                            const bool have = wm != 0ull;
+                            if (!have && nsl == 0u) break;
+                            uint64_t m_ = 0ull;
+                            uint32_t cnt_ = 0;
+                            float vrec = 0.0f;
+                            if (have) {
+                                const uint32_t b = (uint32_t)__builtin_ctzll(wm);
+                                wm = clear_bit64(wm, b);
+                                const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
+                                const uint32_t roff = pidx << 6;
+                                // the two records once more by a VECTOR load, for their LDS copy (the scalar cache does not feed LDS):
+                                // lanes 0-15 the record's dwords, 16-31 the eye record's
+                                if (lane < 32u) vrec = *(const float*)((const char*)((lane < 16u) ? (const void*)a.rec : (const void*)a.erec) + roff + (lane & 15u) * 4u);
+                                float4 r0, r1, r2, r3, e0, e1, e2, e3;
+                                sload64(a.rec, roff, r0, r1, r2, r3);
+                                sload64(a.erec, roff, e0, e1, e2, e3);
+                                (void)e1; (void)e2; (void)e3; (void)r0;
+                                if (COUNT) c.fetches += 8;
+                                m33 A;
+                                A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+                                A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+                                A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+                                const f3 o_g = mk3(e0.x, e0.y, e0.z);
+                                const f3 d_g = matvec(A, d);
+                                const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
+                                m_ = (wave_ballot(e0.w <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * e0.w)) & alivem_;
+                                if (!m_) continue;
+                                cnt_ = (uint32_t)__popcll(m_);
+                                if (COUNT && alive) c.proxy_tests++;
+                            }
+                            if (nsl != 0u && (!have || npr + cnt_ > 64u || nsl == 4u)) {
+                                // ---- one pass over the listed pairs: lanes = (ray, particle) pairs ----
+                                {
+                                    const bool pv = lane < npr;
+                                    const uint32_t pe = pv ? pr_list[lane] : 0u;
+                                    const int pray = (int)(pe & 63u);
+                                    const f3 dd = mk3(__shfl(d.x, pray), __shfl(d.y, pray), __shfl(d.z, pray));
+                                    const float4* sp = (const float4*)(pr_stg + (pe >> 6) * 32u);
+                                    // (three rounds of LDS reads, fenced so that the compiler does not hoist all 32 dwords at once:
+                                    //  the kernel sits at its register limit)
+                                    f3 dg2;
+                                    {
+                                        const float4 q1 = sp[1], q2 = sp[2], q3 = sp[3];
+                                        m33 A2;
+                                        A2.a[0] = q1.x; A2.a[1] = q1.y; A2.a[2] = q1.z;
+                                        A2.a[3] = q2.x; A2.a[4] = q2.y; A2.a[5] = q2.z;
+                                        A2.a[6] = q3.x; A2.a[7] = q3.y; A2.a[8] = q3.z;
+                                        dg2 = matvec(A2, dd);
+                                    }
+                                    wave_fence();
+                                    float te2, tx2;
+                                    bool h2;
+                                    {
+                                        const float4 f1 = sp[5], f2 = sp[6], f3q = sp[7];
+                                        const float s2 = pr_stg[(pe >> 6) * 32u + 3u];
+                                        float pa2[10];
+                                        pa2[0] = f1.x; pa2[1] = f1.y; pa2[2] = f1.z; pa2[3] = f1.w; pa2[4] = f2.x; pa2[5] = f2.y; pa2[6] = f2.z;
+                                        pa2[7] = f2.w; pa2[8] = f3q.x; pa2[9] = f3q.y;
+                                        h2 = proxy_slabs_pre(pa2, dg2, s2, te2, tx2) && pv;
+                                    }
+                                    wave_fence();
+                                    float al2;
+                                    {
+                                        const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], f0 = sp[4];
+                                        m33 A2;
+                                        A2.a[0] = q1.x; A2.a[1] = q1.y; A2.a[2] = q1.z;
+                                        A2.a[3] = q2.x; A2.a[4] = q2.y; A2.a[5] = q2.z;
+                                        A2.a[6] = q3.x; A2.a[7] = q3.y; A2.a[8] = q3.z;
+                                        al2 = fminf(0.99f, response_from(A2, mk3(q0.x, q0.y, q0.z), o, dd, mk3(f0.x, f0.y, f0.z), dg2) * q1.w);
+                                    }
+                                    if (pv) { pr_res[lane] = h2 ? te2 : INFINITY; pr_res[64u + lane] = tx2; pr_res[128u + lane] = al2; }
+                                    wave_fence();
+                                }
+                                // ---- the results back to the rays: one insert round per staged survivor, lanes = rays ----
+                                uint32_t pb = 0;
+                                for (uint32_t sl = 0; sl < nsl; sl++) {
+                                    const uint2 mk = pr_mask[sl];
+                                    const uint64_t m2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.x) |
+                                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.y) << 32);
+                                    const uint32_t pid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pr_stg[sl * 32u + 11u]));
+                                    const bool mine = ((m2 >> lane) & 1ull) != 0ull;
+                                    const uint32_t q_ = pb + lanes_below(m2);
+                                    float te = INFINITY, tx = 0.0f, al = 0.0f;
+                                    if (mine) { te = pr_res[q_]; tx = pr_res[64u + q_]; al = pr_res[128u + q_]; }
+                                    const bool hit = mine && (te <= tx) && alive;
+                                    pb += (uint32_t)__popcll(m2);
+                                    GRT_TILE_INSERT(te, tx, hit, pid, al, 0.0f, mk3(0, 0, 0), mk3(0, 0, 0), 0u)
+                                }
+                                wave_fence();
+                                nsl = 0u;
+                                npr = 0u;
+                            }
+                            if (!have) break;
+                            // ---- stage the survivor: its records, its pairs, its mask ----
+                            if (lane < 32u) pr_stg[nsl * 32u + lane] = vrec;
+                            if ((m_ >> lane) & 1ull) pr_list[npr + lanes_below(m_)] = lane | (nsl << 6);
+                            if (lane == 0u) pr_mask[nsl] = make_uint2((uint32_t)m_, (uint32_t)(m_ >> 32));
+                            wave_fence();
+                            npr += cnt_;
+                            nsl++;
+                        }
+                        continue;
+                    }
                     while (SINGLE ? trip : (wm != 0ull)) {
                         trip = false;
                         float4 r0, r1, r2, r3, e0, e1, e2, e3;
@@ -1210,73 +1403,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #ifdef GRT_TILE_DIAG2
                         if (COUNT) { const uint64_t hm_ = wave_ballot(hit); w.hit_evals += (uint32_t)__popcll(hm_); w.node_visits += hm_ ? 1u : 0u; }
 #endif
-                        const uint32_t id = __float_as_uint(r2.w);
-                        const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
-                        // float compares first: te/tx may be negative or NaN, the unsigned key compares assume t > 0
-                        // (> last_key, not just > pass_lo: a particle that entered the tree as several pieces is met once per
-                        //  piece the tile crosses, with the same keys; what was composited already is not taken again)
-                        const uint64_t seen_ = PIECES ? last_key : pass_lo;
-                        bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > seen_);
-                        bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > seen_);
-                        const uint32_t cellb = PIECES ? __float_as_uint(r3.w) : 0u;
-                        if (PIECES && cellb) { // a piece of a split proxy (wave-uniform but in MODE 2): it reports the particle only when the
-                                     // lane's first pending event lies in ITS cell (piece_owns, grt_device.h)
-                            const bool own_ = piece_owns(cellb, r0.w, o_g, d_g, in_e ? te : tx);
-                            in_e = in_e && own_;
-                            in_x = in_x && own_;
-                        }
-                        const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); // the slot's first pending event
-                        const bool ins = (k_first != kKeyInvalid) && (k_first < lost);
-#ifdef GRT_TILE_CHECK
-                        if (ins && key_t(k_first) < F) c.stall_exits++; // finality violated: an event below the front turned up late
-#endif
-                        if (wave_any(ins)) { // wave-uniform branch
-                            // alpha does not depend on the hit distance (shaders/tracer.cuh:354-357)
-                            const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
-                            const float other = (in_e && in_x) ? tx : INFINITY;
-                            // window full: the largest pending key is dropped (the new one or the last slot's) and
-                            // the lane becomes lossy beyond it
-                            const bool full = KLAST != kKeyInvalid;
-                            const bool take = ins && (!full || k_first < KLAST);
-                            const bool drop = ins && full; // the farthest of (window + new particle) leaves the window
-                            const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
-                            if (wave_any(drop)) { // wave-uniform branch: into the lane's bag
-                                if (!SINGLE && chunk == kNoRoot) { // first overflow of this tile: take a chunk of the pool
-                                    uint32_t ch = 0;
-                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u);
-                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
-                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); // pool exhausted: drop for good
-                                }
-                                const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost);
-                                if (to_bag) {
-                                    const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
-                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
-                                        make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a);
-                                    nb++;
-                                    bagmin = (dk < bagmin) ? dk : bagmin;
-                                }
-                                const bool gone = drop && !to_bag;
-                                lost = (gone && (dk < lost)) ? dk : lost;
-                                if (SINGLE) lost = wave_umin64(lost); // one ray: one cut-off
-                                else bags = true;
-                                if (wave_any(gone)) lim_dirty = true;
-                            }
-                            KLAST = (take && full) ? kKeyInvalid : KLAST;
-                            pmask = take ? (pmask | (1u << cell)) : pmask;
-                            if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; }
-                            if (SINGLE && take) { // the event's radiance travels with it (fetched 64 at a time, not one per event)
-                                f3 L;
-                                if (!SH) {
-                                    const float4 cc = a.color0[id];
-                                    L = mk3(cc.x, cc.y, cc.z);
-                                } else {
-                                    L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max);
-                                }
-                                PL_COL(cell, 0) = L.x; PL_COL(cell, 1) = L.y; PL_COL(cell, 2) = L.z;
-                            }
-                            SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid)
-                        }
+                        GRT_TILE_INSERT(te, tx, hit, __float_as_uint(r2.w), fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w), r0.w, o_g, d_g, __float_as_uint(r3.w))
                     }
 #ifdef GRT_TILE_DIAG2
                     if (COUNT) { w.rounds += (d2_sum + 63u) / 64u; w.stall_exits += d2_passes; }
@@ -1467,6 +1594,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 }
 
 #undef GRT_IN_PART
+#undef GRT_TILE_INSERT
+#undef GRT_TILE_CHECK_FRONT
 #undef KS
 #undef KLAST
 #undef KPRESS

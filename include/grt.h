@@ -183,11 +183,14 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
                                          segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
                                          finishes it (default 128).  Same image for every value */,
-       GRT_OPT_TILE_PARTS2_X2 = 26    /* tile kernel, camera rays without meshes: an 8x8 tile whose cost in the previous frame exceeded
-                                         value/2 x the median tile cost is launched as TWO waves of 4x8 pixels (half the rays each, a
-                                         narrower frustum): the frame's critical path is its heaviest tile.  Default 8 (4 x the median);
-                                         0 = never.  Pixels never depend on it */,
-       GRT_OPT_TILE_PARTS4_X2 = 27    /* ... above value/2 x the median: FOUR waves of 4x4 pixels.  Default 16; 0 = never */ };
+       GRT_OPT_TILE_PARTS4_PCT = 27   /* tile kernel, camera rays without meshes: an 8x8 tile whose cost in the previous frame exceeded
+                                         value % of the heaviest tile's — and GRT_OPT_TILE_PARTS_LOAD_PCT % of the launch's total cost per
+                                         resident wave — is launched as FOUR waves of 4x4 pixels (a quarter of the rays each, a narrower
+                                         frustum).  A frame takes at least its longest tile; a frame bound by its total work (1080p on
+                                         one GPU) splits nothing.  Default 60; 0 = never.  Pixels never depend on it */,
+       GRT_OPT_TILE_PARTS2_PCT = 26   /* ... above value % of the heaviest (and below the four-way threshold): TWO waves of 4x8 pixels.
+                                         Default 0 = never (half a heavy tile takes as long as the whole) */,
+       GRT_OPT_TILE_PARTS_LOAD_PCT = 28 /* see GRT_OPT_TILE_PARTS4_PCT (default 75; 0 = no such condition) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -24,7 +24,7 @@ for wl in sys.argv[1:]:
     acts, center, mesh = bench.build_scene(grt, wl)
     p = grt.default_params(W, H, center, fisheye=fisheye, max_bounces=mb)
     tr = grt.Tracer(0); tr.upload(acts)
-    tr.set_option(grt.OPT_TILE_PARTS2_X2, 0); tr.set_option(grt.OPT_TILE_PARTS4_X2, 0)
+    tr.set_option(grt.OPT_TILE_PARTS2_PCT, 0); tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)
     full = ms_of(tr, p, (0, 0, W, H))
     # coarse: 64x64 windows; then the 8x8 tiles of the slowest three
     coarse = []

@@ -67,11 +67,11 @@ def test_options_do_not_change_pixels():
 
 
 def test_heavy_tiles_as_part_waves_give_the_same_frame():
-    """GRT_OPT_TILE_PARTS2_X2 / _PARTS4_X2: an 8x8 tile that was heavy in the previous frame runs as two waves of 4x8 pixels or
-    four of 4x4.  Pure scheduling: full frames, windows and rank tile lists must not change by a byte, whatever the
-    thresholds (so low here that nearly every tile is split; four-way only; two-way only; more parts than the launch has room
-    for, which demotes them), frame after frame (a split tile's cost word is scaled back so that it stays split), and the
-    per-ray counters must be those of whole tiles."""
+    """GRT_OPT_TILE_PARTS4_PCT / _PARTS2_PCT / _PARTS_LOAD_PCT: an 8x8 tile that was heavy in the previous frame runs as four waves
+    of 4x4 pixels or two of 4x8.  Pure scheduling: full frames, windows and rank tile lists must not change by a byte, whatever
+    the thresholds (so low here that nearly every tile is split; four-way only; two-way only; a band of each; more parts than
+    the launch has room for: the heaviest classes get them), frame after frame (a split tile's cost word is scaled back so that it
+    stays split), and the per-ray counters (rays, segments, consumed hits) must be those of whole tiles."""
     import torch
     acts, p, sc, op, _ = make_scene(31, 30000, 200, 136, scale_boost=0.45)
     tr = grt.Tracer(0)
@@ -83,9 +83,10 @@ def test_heavy_tiles_as_part_waves_give_the_same_frame():
     c0 = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
     w8 = torch.zeros_like(ref8)
-    for v2, v4 in ((1, 0), (1, 1), (0, 1), (3, 6), (2, 5), (8, 24)):
-        tr.set_option(grt.OPT_TILE_PARTS2_X2, v2)
-        tr.set_option(grt.OPT_TILE_PARTS4_X2, v4)
+    for v2, v4, vl in ((1, 0, 0), (1, 1, 0), (0, 1, 0), (10, 40, 0), (20, 60, 50), (0, 70, 75), (5, 5, 100)):
+        tr.set_option(grt.OPT_TILE_PARTS2_PCT, v2)
+        tr.set_option(grt.OPT_TILE_PARTS4_PCT, v4)
+        tr.set_option(grt.OPT_TILE_PARTS_LOAD_PCT, vl)
         for it in range(4):
             a8, af = tr.render(p, want_f32=True)
             assert (a8 == ref8).all() and (af == reff).all(), (v2, v4, it)

@@ -79,6 +79,7 @@ def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
     acts, p, sc = _dense_cluster_camera()
     tr = grt.Tracer(0)
     tr.upload(acts)
+    tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)  # whole tiles: one chunk per tile at most (a tile launched as part waves takes one per part)
     tr.set_option(grt.OPT_COUNTERS, 1)
     ref8, reff = tr.render(p, want_f32=True)
     ref8, reff = ref8.clone(), reff.clone()
