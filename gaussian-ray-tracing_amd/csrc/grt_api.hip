@@ -1067,7 +1067,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_cap = 0;
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
-        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units))));
+        CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u))); // (+ 3 diagnostic words)
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
     }
@@ -1081,9 +1081,15 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
     }
     const bool same = c->cost_valid && memcmp(sig, c->cost_sig, sizeof(sig)) == 0;
     const grt_ctx* sc = scene_of(c);
-    if (same && c->order_ready && c->order_epoch == sc->scene_epoch && memcmp(&c->order_params, &a.p, sizeof(grt_params)) == 0) {
-        // the very frame the order was made from (same scene, camera, options): a tile's cost does not depend on the launch
-        // order, so this frame would measure the same costs and make the same order again — keep it, collect nothing
+    // was the order this frame is launched with made for THIS frame (same scene, camera, options)?  Remembered for the order that
+    // will be made from this frame's costs: costs measured under another view's part waves — its heavy tiles split, this view's not —
+    // make an order that is one feedback step short of the fixed point (a 256^2 frame after a camera move: 0.61 instead of 0.53 ms,
+    // for as long as the view stands still), so such an order is used but not KEPT: the next identical frame collects once more.
+    const bool order_is_for_this_frame = c->order_valid && c->order_epoch == sc->scene_epoch && memcmp(&c->order_params, &a.p, sizeof(grt_params)) == 0;
+    c->launch_order_matched = same && order_is_for_this_frame; // (a frame without usable costs runs in the cold order: no match)
+    if (same && c->order_ready && c->order_settled && order_is_for_this_frame) {
+        // the very frame the order was made from: a tile's cost does not depend on the launch order (nor, once settled, on which
+        // tiles run as parts), so this frame would measure the same costs and make the same order again — keep it, collect nothing
         a.order = c->d_order;
         a.n_launch = c->order_launch;
         if (c->order_split) a.n_heavy = c->d_n_heavy;
@@ -1301,9 +1307,26 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     }
     {
         static const bool dbg = getenv("GRT_DEBUG_LAUNCH") != nullptr; // one line per frame on stderr: what the launch is made of
-        if (dbg)
-            fprintf(stderr, "grt launch: ctx %p mode %u units %u order %s entries %u cost %s parts_ok %d cost_valid %d order_ready %d\n", (void*)c, a.mode,
-                    a.n_units, a.order ? "yes" : "no", a.n_launch, a.cost ? "collect" : "-", (int)c->parts_ok, (int)c->cost_valid, (int)c->order_ready);
+        if (dbg) {
+            uint32_t d3[3] = {0, 0, 0}; // entries in use, four-way threshold, heaviest tile (as the ordering kernel left them)
+            if (a.order && a.n_launch) { (void)hipDeviceSynchronize(); (void)hipMemcpy(d3, c->d_order + a.n_launch, sizeof(d3), hipMemcpyDeviceToHost); }
+            fprintf(stderr, "grt launch: ctx %p mode %u units %u order %s entries %u cost %s parts_ok %d cost_valid %d order_ready %d used %u thr4 %u max %u\n",
+                    (void*)c, a.mode, a.n_units, a.order ? "yes" : "no", a.n_launch, a.cost ? "collect" : "-", (int)c->parts_ok, (int)c->cost_valid,
+                    (int)c->order_ready, d3[0], d3[1], d3[2]);
+            static const bool dbg2 = getenv("GRT_DEBUG_LAUNCH")[0] == '2'; // ... and the launch order's parts
+            if (dbg2 && a.order && a.n_launch) {
+                std::vector<uint32_t> ord(a.n_launch);
+                (void)hipMemcpy(ord.data(), c->d_order, sizeof(uint32_t) * a.n_launch, hipMemcpyDeviceToHost);
+                uint32_t n4 = 0, n2 = 0;
+                std::string head, tiles4;
+                for (uint32_t i = 0; i < d3[0] && i < a.n_launch; i++) {
+                    const uint32_t e = ord[i], code = e >> 30, part = (e >> 28) & 3u, unit = e & kOrderUnitMask;
+                    if (part == 0u) { n4 += code == 2u; n2 += code == 1u; }
+                    if (part == 0u && head.size() < 300) head += " " + std::to_string(unit) + (code ? "/" + std::to_string(code) : "");
+                }
+                fprintf(stderr, "grt order: four-way %u two-way %u first:%s\n", n4, n2, head.c_str());
+            }
+        }
     }
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
@@ -1316,10 +1339,25 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         hipLaunchKernelGGL(k_check_costs, dim3((a.n_units + 255u) / 256u), dim3(256), 0, s, c->d_cost, a.n_units, a.max_iters, c->d_err);
         tail = true;
     }
+    if (rc == GRT_OK && a.cost && c->cost_valid && getenv("GRT_DEBUG_LAUNCH") && getenv("GRT_DEBUG_LAUNCH")[0] == '2') {
+        // diagnostics: the heaviest tiles of the frame just rendered (steps / part code) before the costs are consumed
+        (void)hipStreamSynchronize(s);
+        std::vector<uint32_t> h(a.n_units);
+        (void)hipMemcpy(h.data(), c->d_cost, sizeof(uint32_t) * a.n_units, hipMemcpyDeviceToHost);
+        std::vector<uint32_t> idx(a.n_units);
+        for (uint32_t i = 0; i < a.n_units; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return (h[x] & kCostStepsMask) > (h[y] & kCostStepsMask); });
+        std::string t;
+        for (uint32_t k = 0; k < 24 && k < a.n_units; k++)
+            t += " " + std::to_string(idx[k]) + ":" + std::to_string(h[idx[k]] & kCostStepsMask) + "/" + std::to_string((h[idx[k]] >> kCostPartShift) & 3u);
+        fprintf(stderr, "grt costs (unit:steps/code, by raw steps):%s\n", t.c_str());
+    }
     if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order
         if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
             c->order_ready = true;
             c->order_valid = true;
+            // (settled: this frame itself ran with an order made for it — or no tile is ever split, and costs do not depend on the order)
+            c->order_settled = c->launch_order_matched || c->order_launch == 0;
             c->order_params = a.p;
             c->order_epoch = sc->scene_epoch;
             // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)

@@ -548,15 +548,16 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
             ok4[b] = (e4 != 0u && extras + e4 <= extra_cap) ? 1 : 0;
             if (ok4[b]) extras += e4;
         }
+        const bool two_way = s_t2 != 0xFFFFFFFFu; // (two-way parts are in use at all: only then may a four-way class fall back to them)
         for (uint32_t b = 0; b < 128u; b++) {
-            const uint32_t e2 = h2[b] + (ok4[b] ? 0u : h4[b]);
+            const uint32_t e2 = h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u);
             ok2[b] = (e2 != 0u && extras + e2 <= extra_cap) ? 1 : 0;
             if (ok2[b]) extras += e2;
         }
         uint32_t acc = 0;
-        for (uint32_t b = 0; b < 128u; b++) {
+        for (uint32_t b = 0; b < 128u; b++) { // (exactly what the scatter below writes: a gap would leave a stale entry in the launch)
             cursor[b] = acc;
-            acc += hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + (ok4[b] ? 0u : h4[b]) : 0u);
+            acc += hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u) : 0u);
         }
         s_total = acc;
     }
@@ -565,7 +566,8 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
         const uint32_t i = base + tid;
         if (i < n) {
             const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
-            const uint32_t code = (r > t4 && ok4[b]) ? 2u : ((r > t2 && ok2[b]) ? 1u : 0u);
+            const bool two_way = t2 != 0xFFFFFFFFu;
+            const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
             const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
             const uint32_t pos = atomicAdd(&cursor[b], parts);
             for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
@@ -573,6 +575,7 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
         __syncthreads();
     }
     for (uint32_t i = s_total + tid; i < n + extra_cap; i += 1024u) order[i] = kOrderPad;
+    if (tid == 0u) { order[n + extra_cap] = s_total; order[n + extra_cap + 1u] = s_t4; order[n + extra_cap + 2u] = s_max; } // (diagnostics: GRT_DEBUG_LAUNCH)
 }
 
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,

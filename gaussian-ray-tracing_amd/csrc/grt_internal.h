@@ -256,6 +256,8 @@ struct grt_ctx {
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
+    bool launch_order_matched = false; // the current launch's order had been made for this very frame (scene, camera, options)
+    bool order_settled = false;        // ... and so had the frame d_order was made from: the order may be kept for repeats of it
     uint32_t* d_err = nullptr;    // sticky device error word (RenderArgs::err_word)
     uint32_t* h_err = nullptr;    // pinned copy of it, refreshed behind every frame on the frame's stream (read after ev_tail)
     hipStream_t tail_stream = nullptr; // stream the post-frame work (next order, zeroing) was queued on

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     // k_cost_order_parts) — the wave then traces the tile's upper / lower 4 rows, or one of its 4x4 quadrants, and the other
     // lanes carry no ray; entries past the last one are padding
     const uint32_t ue = (a.order && !BUNDLE) ? a.order[rank] : unit_s;
-    if (!BUNDLE && ue == kOrderPad) break; // wave-uniform
+    if (!BUNDLE && a.order && (ue & kOrderUnitMask) >= a.n_units) break; // padding (kOrderPad), or anything that is not a tile of this launch
     const uint32_t unit = BUNDLE ? ue : (ue & kOrderUnitMask);
     // (lane = 8 row + column: bit 5 = lower half of the tile, bit 2 = right half; formed from `ue` where it is needed — at the
     //  ray set-up and at the pixel write — so that nothing but `ue` lives across the passes)
