@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const bool occ_l = fr != kNoRoot;
                 const bool rng_l = occ_l && ((fr & kLeafBit) != 0u);
                 bool leaf_step;
+                bool dense_ = false;      // GRT_TILE_DEFER: this leaf step had more candidate ranges than it can take (nearest ones chosen)
+                float step_th = INFINITY; // ... and the box bound of the farthest range it took
+                (void)dense_; (void)step_th;
                 uint32_t nref; // the entry this lane's group expands
                 uint32_t ngrp; // groups in this step (wave-uniform): group g is valid when g < ngrp
                 uint32_t g, j; // group of this lane and its child slot in the group: 4 lanes per leaf range, kTileWide per node
@@ -1115,7 +1118,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         }
                         th = lo_;
                         sm = candm_ & wave_ballot(fl <= th);
+                        dense_ = leaf_step;
                     }
+                    step_th = th;
                     const bool selm = cand && (fl <= th);
                     const uint32_t rk = lanes_below(sm);
                     const bool sel = selm && (rk < maxb);
@@ -1201,6 +1206,71 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
 #ifdef GRT_TILE_DIAG2
                     uint32_t d2_sum = 0, d2_prev = 0, d2_passes = 0;
+#endif
+#ifdef GRT_TILE_DEFER
+                    // EXPERIMENT (profiles/r04_experiments_log.md, item 9): an order among overlapping proxies.  In a dense region the step
+                    // takes the nearest ranges BY BOX, and a box's bound is early by up to a proxy's diameter: hundreds of proxies are
+                    // slab-tested before the rays — which saturate a few dozen events in — ever reach them.  So when the step had to choose
+                    // (more candidates than it can take), every survivor is first given a TIGHT lower bound of its entry: the smallest
+                    // entry into its circumscribed sphere in Gaussian space over the lanes the pre-test lets through (the quantities the
+                    // pre-test forms anyway).  A range whose surviving particles all start beyond the box bound of the farthest range
+                    // taken goes back on the frontier with that bound — other ranges are nearer than it — and one that no lane can touch
+                    // is dropped; the rest is tested as ever.  A range is deferred at most once (its bound is tight from then on).
+                    if (!SINGLE && dense_ && wm != 0ull) {
+                        float lamp = INFINITY;
+                        uint64_t w1 = wm;
+                        const uint64_t alive1_ = wave_ballot(alive);
+                        while (w1 != 0ull) {
+                            const uint32_t b = (uint32_t)__builtin_ctzll(w1);
+                            w1 = clear_bit64(w1, b);
+                            const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b) << 6;
+                            float4 r0, r1, r2, r3, e0, e1, e2, e3;
+                            sload64(a.rec, roff, r0, r1, r2, r3);
+                            if (!BUNDLE) sload64(a.erec, roff, e0, e1, e2, e3);
+                            if (COUNT) c.fetches += BUNDLE ? 4 : 8;
+                            m33 A;
+                            A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
+                            A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
+                            A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
+                            const f3 o_g = BUNDLE ? matvec(A, sub3(o, mk3(r0.x, r0.y, r0.z))) : mk3(e0.x, e0.y, e0.z);
+                            const float cc_ = BUNDLE ? proxy_sphere_cc(o_g, r0.w) : e0.w;
+                            const f3 d_g = matvec(A, d);
+                            const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
+                            const bool inside_ = cc_ <= 0.0f;
+                            const bool pass_ = alive && (inside_ || (b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_));
+                            // first root of aa t^2 + 2 b t + cc = 0; outside and moving away (b >= 0): the sphere lies behind the ray
+                            const float disc_ = fmaxf(b_ * b_ - aa_ * cc_, 0.0f);
+                            const float tsp_ = (-b_ - __builtin_amdgcn_sqrtf(disc_)) * __builtin_amdgcn_rcpf(fmaxf(aa_, 1e-30f));
+                            const float tl_ = inside_ ? 0.0f : ((b_ < 0.0f) ? fmaxf(tsp_ * (1.0f - 4e-5f) - 1e-30f, 0.0f) : INFINITY);
+                            const float lp_ = uni(wave_fmin((pass_ && (alive1_ != 0ull)) ? tl_ : INFINITY));
+                            lamp = (lane == b) ? lp_ : lamp;
+                        }
+                        // the smallest bound among a range's particles (4 lanes per range; non-negative floats order as integers)
+                        uint32_t lq = __float_as_uint(want ? lamp : INFINITY);
+                        lq = min(lq, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lq, 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+                        lq = min(lq, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lq, 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
+                        const float lamr = __uint_as_float(lq);
+                        const bool none_ = !(lamr < INFINITY);               // no lane can touch any particle of the range
+                        const bool later_ = !none_ && (lamr > step_th);       // its particles start beyond what this step reaches
+                        const bool back_ = later_ && gv && (j == 0u) && (fmaxf(lamr, F) <= LIM);
+                        const uint64_t backm = wave_ballot(back_);
+                        if (backm) { // back onto the frontier (the step freed at least as many slots as it took ranges)
+                            const uint32_t crk = lanes_below(backm);
+                            if (back_) xch[crk] = make_uint2(__float_as_uint(fmaxf(lamr, F)), nref);
+                            wave_fence();
+                            const uint64_t fm = wave_ballot(fr == kNoRoot);
+                            const uint32_t frk = lanes_below(fm);
+                            if ((fr == kNoRoot) && (frk < (uint32_t)__popcll(backm))) {
+                                const uint2 v = xch[frk];
+                                fl = __uint_as_float(v.x);
+                                fr = v.y;
+                            }
+                            wave_fence();
+                        }
+                        wm &= ~(wave_ballot(none_) | wave_ballot(later_));
+                        want = want && !none_ && !later_;
+                        GRT_D(stall_exits, 0)
+                    }
 #endif
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
                     const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
