@@ -416,6 +416,18 @@ static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
 // The tile kernel's give-up reasons travel in the per-tile cost words (see the watchdog in grt_render_tile.hip): a cost
 // above the step watchdog = the watchdog fired, high bits = stack guard / two passes without progress.  One pass over
 // the costs right behind the frame ORs them into the context's sticky error word.
+// behind every frame (do_launch): error word and overflow demand to their pinned host words, overflow counter reset
+__global__ void k_frame_tail(const uint32_t* __restrict__ d_err, uint32_t* __restrict__ h_err, uint32_t* __restrict__ d_ovf_next,
+                             uint32_t* __restrict__ h_ovf_used)
+{
+    *h_err = *d_err;
+    if (d_ovf_next) {
+        *h_ovf_used = *d_ovf_next;
+        *d_ovf_next = 0u;
+    }
+    __threadfence_system();
+}
+
 __global__ void k_check_costs(const uint32_t* __restrict__ cost, uint32_t n, uint32_t max_iters, uint32_t* __restrict__ err_word)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1025,8 +1037,9 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // launch order of the units from the costs the last frame left in d_cost (dilated for full-frame launches)
 static uint32_t parts_extra_cap(uint32_t n_units) { return n_units / 4u + 64u; } // launch entries beyond one per tile
 
-static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, hipStream_t s, bool* used_split)
+static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, hipStream_t s, bool* used_split, bool zero_costs = false)
 {
+    uint32_t* d_zero = zero_costs ? c->d_cost : nullptr; // (the ordering kernel zeroes the consumed costs itself: one packet less)
     const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
     const uint32_t* cost_src = c->d_cost;
     if (c->opt_cost_radius > 0 && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
@@ -1040,13 +1053,13 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         *used_split = false;
         const uint32_t cap = parts_extra_cap(n_units);
         int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
-                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, s, &c->err);
+                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, s, &c->err);
         if (rcp == GRT_OK) c->order_launch = n_units + cap;
         return rcp;
     }
     *used_split = split;
     return order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
-                               (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, s, &c->err);
+                               (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, d_zero, s, &c->err);
 }
 
 static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n_units, bool need_cost)
@@ -1123,7 +1136,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             if (rcd != GRT_OK) return rcd;
             src = c->d_cost;
         }
-        int rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, s, &c->err);
+        int rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, nullptr, s, &c->err);
         if (rc != GRT_OK) return rc;
         a.order = c->d_order;
         c->order_launch = 0;
@@ -1353,29 +1366,33 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         fprintf(stderr, "grt costs (unit:steps/code, by raw steps):%s\n", t.c_str());
     }
     if (rc == GRT_OK && a.cost && c->cost_valid) { // the next frame's launch order
-        if (order_from_costs(c, a, a.n_units, s, &c->order_split) == GRT_OK) {
+        if (order_from_costs(c, a, a.n_units, s, &c->order_split, true) == GRT_OK) {
             c->order_ready = true;
             c->order_valid = true;
             // (settled: this frame itself ran with an order made for it — or no tile is ever split, and costs do not depend on the order)
             c->order_settled = c->launch_order_matched || c->order_launch == 0;
             c->order_params = a.p;
             c->order_epoch = sc->scene_epoch;
-            // ... and the zeroing the next frame needs before its first wave (costs consumed, bag counter)
-            if (hipMemsetAsync(c->d_cost, 0, sizeof(uint32_t) * a.n_units, s) == hipSuccess) c->cost_zeroed = true;
+            // ... and the zeroing the next frame needs before its first wave: done by the ordering kernel itself (costs consumed)
+            c->cost_zeroed = true;
             tail = true;
         }
     }
-    if (rc == GRT_OK && a.ovf_next) {
-        // the chunks this frame asked for -> pinned host word (sizes the pool of the frames to come), then the reset
-        if (!c->ovf_pending && hipMemcpyAsync(c->h_ovf_used, c->d_ovf_next, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
-            hipEventRecord(c->ev_ovf, s) == hipSuccess)
-            c->ovf_pending = true;
-        if (hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s) == hipSuccess) c->ovf_zeroed = true;
-        tail = true;
+    // ONE single-thread kernel behind the frame (it was two copies and a memset, each a packet of its own on the queue): the sticky
+    // error word as the frame and k_check_costs left it -> pinned host word (grt_sync reads it behind ev_tail: no blocking
+    // null-stream copy, which waited for every other frame slot's stream too); the overflow chunks this frame asked for -> pinned
+    // host word (sizes the pool of the frames to come), and their counter reset for the next frame
+    {
+        uint32_t* ovf = (rc == GRT_OK) ? a.ovf_next : nullptr;
+        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->h_ovf_used);
+        if (hipGetLastError() == hipSuccess) {
+            tail = true;
+            if (ovf) {
+                c->ovf_zeroed = true;
+                if (!c->ovf_pending && hipEventRecord(c->ev_ovf, s) == hipSuccess) c->ovf_pending = true;
+            }
+        }
     }
-    // the sticky error word as the frame (and k_check_costs) left it -> pinned host word, on the frame's stream: grt_sync
-    // reads it behind ev_tail without a blocking null-stream copy (which waited for every other frame slot's stream too)
-    if (hipMemcpyAsync(c->h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess) tail = true;
     if (tail && hipEventRecord(c->ev_tail, s) == hipSuccess) { c->tail_pending = true; c->tail_stream = s; }
     return rc;
 }

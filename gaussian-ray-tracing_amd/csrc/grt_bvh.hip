@@ -457,7 +457,7 @@ __device__ __forceinline__ uint32_t cost_class_floor(uint32_t k)
 
 __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict__ cost, uint32_t n,
                                                      uint32_t* __restrict__ order, uint32_t cap, uint32_t thr_x2,
-                                                     uint32_t* __restrict__ n_heavy)
+                                                     uint32_t* __restrict__ n_heavy, uint32_t* __restrict__ zero)
 {
     __shared__ uint32_t hist[128], cursor[128];
     const uint32_t tid = threadIdx.x;
@@ -487,6 +487,8 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
         if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost_eff(cost[i]))], 1u)] = i;
         __syncthreads();
     }
+    // the costs are consumed: zero them for the next frame here (one packet less behind every frame that collects costs)
+    if (zero) for (uint32_t i = tid; i < n; i += 1024u) zero[i] = 0u;
 }
 
 // The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes).  A frame takes at least
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
 // entries beyond one per tile: they go to the heaviest cost classes first.
 __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n,
                                                            uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t pct2, uint32_t pct4,
-                                                           uint32_t pct_load, uint32_t resident_waves)
+                                                           uint32_t pct_load, uint32_t resident_waves, uint32_t* __restrict__ zero)
 {
     __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
     __shared__ uint8_t ok4[128], ok2[128]; // the launch has room for this cost class's four-way / two-way parts
@@ -576,14 +578,16 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
     }
     for (uint32_t i = s_total + tid; i < n + extra_cap; i += 1024u) order[i] = kOrderPad;
     if (tid == 0u) { order[n + extra_cap] = s_total; order[n + extra_cap + 1u] = s_t4; order[n + extra_cap + 2u] = s_max; } // (diagnostics: GRT_DEBUG_LAUNCH)
+    if (zero) for (uint32_t i = tid; i < n; i += 1024u) zero[i] = 0u; // (costs consumed; every thread is past its last read of them: the loop above ends in a barrier)
 }
 
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, hipStream_t stream, std::string* err)
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, hipStream_t stream,
+                           std::string* err)
 {
     if (n == 0) return GRT_OK;
     hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, pct2, pct4, pct_load,
-                       resident_waves);
+                       resident_waves, d_zero);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("order_units_with_parts: ") + hipGetErrorString(e);
@@ -628,10 +632,10 @@ int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uin
 }
 
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
-                        uint32_t* d_n_heavy, hipStream_t stream, std::string* err)
+                        uint32_t* d_n_heavy, uint32_t* d_zero, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
-    hipLaunchKernelGGL(k_cost_order, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, heavy_cap, thr_x2, d_n_heavy);
+    hipLaunchKernelGGL(k_cost_order, dim3(1), dim3(1024), 0, stream, d_cost, n, d_order, heavy_cap, thr_x2, d_n_heavy, d_zero);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("order_units_by_cost: ") + hipGetErrorString(e);

@@ -212,10 +212,12 @@ int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uin
                       std::string* err);
 // launch order with the heaviest tiles as 2 / 4 parts (tile kernel): n + extra_cap entries, padded with kOrderPad
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, hipStream_t stream, std::string* err);
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, hipStream_t stream,
+                           std::string* err);
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
+// (d_zero != nullptr: that array of n cost words is zeroed once the order is made — the costs are consumed)
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
-                        uint32_t* d_n_heavy, hipStream_t stream, std::string* err);
+                        uint32_t* d_n_heavy, uint32_t* d_zero, hipStream_t stream, std::string* err);
 
 }  // namespace grt
 
