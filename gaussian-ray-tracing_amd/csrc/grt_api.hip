@@ -1352,7 +1352,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         hipLaunchKernelGGL(k_check_costs, dim3((a.n_units + 255u) / 256u), dim3(256), 0, s, c->d_cost, a.n_units, a.max_iters, c->d_err);
         tail = true;
     }
-    if (rc == GRT_OK && a.cost && c->cost_valid && getenv("GRT_DEBUG_LAUNCH") && getenv("GRT_DEBUG_LAUNCH")[0] == '2') {
+    static const bool dbg_costs = getenv("GRT_DEBUG_LAUNCH") != nullptr && getenv("GRT_DEBUG_LAUNCH")[0] == '2';
+    if (dbg_costs && rc == GRT_OK && a.cost && c->cost_valid) {
         // diagnostics: the heaviest tiles of the frame just rendered (steps / part code) before the costs are consumed
         (void)hipStreamSynchronize(s);
         std::vector<uint32_t> h(a.n_units);

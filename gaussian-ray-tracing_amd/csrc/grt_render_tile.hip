@@ -143,6 +143,13 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #else
 #define GRT_FIT_DIV4(a, x) ((a) / (x))
 #endif
+// EXPERIMENT (-DGRT_TILE_COLD_HINTS): mark the rare wave-uniform blocks (frontier rebalance, depth-first pops, window-bag
+// pruning and refills, bag spills, later-pass culls) as unlikely, so that block placement moves them out of the hot loop's text.
+#ifdef GRT_TILE_COLD_HINTS
+#define GRT_RARE(x) __builtin_expect(!!(x), 0)
+#else
+#define GRT_RARE(x) (x)
+#endif
 #ifndef GRT_TILE_CHECK_LANE
 #define GRT_TILE_CHECK_LANE 0u
 #endif
@@ -351,7 +358,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
                             const bool take = ins && (!full || k_first < KLAST); \
                             const bool drop = ins && full; \
                             const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask); \
-                            if (wave_any(drop)) { \
+                            if (GRT_RARE(wave_any(drop))) { \
                                 if (!SINGLE && chunk == kNoRoot) { \
                                     uint32_t ch = 0; \
                                     if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u); \
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 uint32_t cur = kNoRoot; // entry taken off the overflow stack (depth-first mode; F stays as it is)
                 if (dsp && !wave_any(alive)) dsp = 0; // every lane is done: nothing on the stack matters any more
                 const bool dfs = dsp != 0u;
-                if (dfs) {
+                if (GRT_RARE(dfs)) {
                     --dsp;
                     cur = dstack[dsp];
                     cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 } else {
                     float Ff = wave_min(fl);
                     Ff_cur = Ff;
-                    if (nbag) {
+                    if (GRT_RARE(nbag)) {
                         const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
                         // (everything but one entry may end up in the bag: only when frontier + bag fit it)
                         if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * look_) && (nocc_ + 8u <= kKeep))) &&
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
                     const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + GRT_PRUNE_ROOM >= a.ovf_entries);
-                    if (wave_any(pr_)) { // wave-uniform, rare
+                    if (GRT_RARE(wave_any(pr_))) { // wave-uniform, rare
                         bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
                         lim_dirty = true;
                     }
@@ -914,7 +921,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                              wave_any(can_ && ((KPRESS != kKeyInvalid) || (T < kSweepEagerT)));
                             if (!go_) break;
                         }
-                        if (!cm_) {
+                        if (GRT_RARE(!cm_)) {
                             // ---- refill: one scan of the bags of the lanes in need; entry by entry, whatever is smaller
                             //      than the window's last key goes in (sorted insert) and the displaced last key takes
                             //      its place in the bag (compacted in place: position w <= i) ----
@@ -1147,7 +1154,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const uint32_t cref = leaf_step ? (first + j) : __float_as_uint(b0.w); // particle index / child ref
                 const bool valid = cv && (cref != kNoRoot);
                 if (COUNT && valid) c.node_visits++; // one 32-B child box per lane
-                if (lim_dirty) { // a window overflowed: lanes past their cutoff want nothing any more
+                if (GRT_RARE(lim_dirty)) { // a window overflowed: lanes past their cutoff want nothing any more
                     const float ct2_ = (lost != kKeyInvalid) ? key_t(lost) : t_hi_m;
                     LIM = uni(wave_fmax(alive ? ct2_ : 0.0f));
                     lim_dirty = false;
@@ -1192,7 +1199,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 lam = fmaxf(lam, F); // never below the current front (keeps the frontier monotone)
                 bool want = valid & inside & (lam <= LIM);
                 uint64_t wm = wave_ballot(g < ngrp) & wave_ballot(j < jmax_) & wave_ballot(cref != kNoRoot) & insidem_ & wave_ballot(lam <= LIM);
-                if (LO > 0.0f) { // later passes: skip what ends before the restart point
+                if (GRT_RARE(LO > 0.0f)) { // later passes: skip what ends before the restart point
                     const float fx_ = fmaxf(fabsf(lx_), fabsf(hx_)), fy_ = fmaxf(fabsf(ly_), fabsf(hy_)),
                                 fz_ = fmaxf(fabsf(lz_), fabsf(hz_));
                     float far = sqrtf(__builtin_fmaf(fx_, fx_, __builtin_fmaf(fy_, fy_, fz_ * fz_))) * (1.0f + 2e-6f);
