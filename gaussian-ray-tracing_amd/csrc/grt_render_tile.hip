@@ -726,24 +726,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             float F = 0.0f;
             float Ff_cur = 0.0f; // minimum of the register part of the frontier (loop top)
             bool done = false;
-
-            while (true) {
-                uint32_t cur = kNoRoot; // entry taken off the overflow stack (depth-first mode; F stays as it is)
-                if (dsp && !wave_any(alive)) dsp = 0; // every lane is done: nothing on the stack matters any more
-                const bool dfs = dsp != 0u;
-                if (GRT_RARE(dfs)) {
-                    --dsp;
-                    cur = dstack[dsp];
-                    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                    GRT_D(node_visits, 1)
-                } else {
-                    float Ff = wave_min(fl);
-                    Ff_cur = Ff;
-                    if (GRT_RARE(nbag)) {
-                        const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
-                        // (everything but one entry may end up in the bag: only when frontier + bag fit it)
-                        if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * look_) && (nocc_ + 8u <= kKeep))) &&
-                            (nocc_ + nbag <= kBag)) {
+            // (the rebalance of frontier + LDS bag, as a lambda: called where the step loop finds it due — or, in the GRT_TILE_REBAL_OUT
+            //  experiment, behind the loop, which is then re-entered)
+            auto do_rebalance = [&](const uint32_t nocc_, float& Ff) {
                             // ---- rebalance: the nearest kKeep entries of (frontier + bag) stay in registers, the rest
                             //      goes (back) to the bag.  Everything passes through registers: 4 bag entries per lane.
                             GRT_D(stall_exits, 1)
@@ -827,6 +812,41 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             rebal = false;
                             Ff = wave_min(fl);
                             Ff_cur = Ff;
+            };
+#ifdef GRT_TILE_REBAL_OUT
+            bool need_rebal = false, skip_rebal = false;
+            for (;;) {
+#endif
+
+            while (true) {
+                uint32_t cur = kNoRoot; // entry taken off the overflow stack (depth-first mode; F stays as it is)
+                if (dsp && !wave_any(alive)) dsp = 0; // every lane is done: nothing on the stack matters any more
+                const bool dfs = dsp != 0u;
+                if (GRT_RARE(dfs)) {
+                    --dsp;
+                    cur = dstack[dsp];
+                    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                    GRT_D(node_visits, 1)
+                } else {
+                    float Ff = wave_min(fl);
+                    Ff_cur = Ff;
+#ifdef GRT_TILE_REBAL_OUT
+                    const bool rb_check_ = nbag != 0u && !skip_rebal;
+                    skip_rebal = false;
+                    if (GRT_RARE(rb_check_)) {
+#else
+                    if (GRT_RARE(nbag)) {
+#endif
+                        const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
+                        // (everything but one entry may end up in the bag: only when frontier + bag fit it)
+                        if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * look_) && (nocc_ + 8u <= kKeep))) &&
+                            (nocc_ + nbag <= kBag)) {
+#ifdef GRT_TILE_REBAL_OUT
+                            need_rebal = true; // EXPERIMENT: leave the step loop; the rebalance runs outside it (below) and the loop is re-entered
+                            break;
+#else
+                            do_rebalance(nocc_, Ff);
+#endif
                         }
                     }
                     F = fminf(Ff, Fbag);
@@ -1527,6 +1547,16 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     }
                 }
             }
+#ifdef GRT_TILE_REBAL_OUT
+            if (!need_rebal) break;
+            need_rebal = false;
+            {
+                float Ff_;
+                do_rebalance((uint32_t)__popcll(wave_ballot(fr != kNoRoot)), Ff_);
+                skip_rebal = true; // (at least one step between two rebalances, as with the in-place call)
+            }
+            } // for (;;)
+#endif
             // a lane goes again only if it dropped something and still has transmittance left
             if (aborted) break;
             const bool progressed = last_key != pass_lo;
