@@ -444,6 +444,17 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     __shared__ float pr_res[PAIRS ? 3 * 64 : 1];  // PAIRS: entry t (+inf: no hit), exit t, alpha of every pair
     __shared__ uint2 pr_mask[PAIRS ? 4 : 1];      // PAIRS: the staged survivors' pre-test lane masks
     (void)pr_stg; (void)pr_list; (void)pr_res; (void)pr_mask;
+#ifndef GRT_TILE_PLANES_SGPR
+#define GRT_TILE_PLANES_LDS 1
+#endif
+#ifdef GRT_TILE_PLANES_LDS
+    // The frustum's twelve plane components and three slab factors live in LDS (64 B: what was left under the 16-waves-per-CU
+    // limit) instead of 21 SGPRs that are alive across every loop of the kernel; the step reads them back by four broadcast
+    // ds_read_b128.  The kernel spilled 22 SGPRs to VGPR lanes; it spills 6 now, and the v_readlane / v_writelane inside loops — whose
+    // static count predicts the frame across builds (profiles/r04_experiments_log.md 10, 11) — went from 171 to 141: C3 -4.5 %, C5 -4.4 %,
+    // C2 -3.7 %, C3a -5.1 %, C4 -2.5 % (round 4).  -DGRT_TILE_PLANES_SGPR: the planes in scalar registers, as before.
+    __shared__ __attribute__((aligned(16))) float fr_lds[16];
+#endif
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
@@ -634,6 +645,17 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             const float il_ = GRT_FIT_NRM(pk_, __builtin_fmaf(x_, x_, __builtin_fmaf(y_, y_, z_ * z_))); \
             P##x = uni(x_ * il_); P##y = uni(y_ * il_); P##z = uni(z_ * il_);                              \
         }
+#ifdef GRT_TILE_PLANES_LDS
+#define GRT_PLANES_TO_LDS                                                                                  \
+            if (lane == 0u) {                                                                              \
+                float4* q_ = (float4*)fr_lds;                                                              \
+                q_[0] = make_float4(pLx, pLy, pLz, pRx); q_[1] = make_float4(pRy, pRz, pBx, pBy);          \
+                q_[2] = make_float4(pBz, pTx, pTy, pTz); q_[3] = make_float4(ivx, ivy, ivz, 0.0f);         \
+            }                                                                                              \
+            wave_fence();
+#else
+#define GRT_PLANES_TO_LDS
+#endif
 #define GRT_FRUSTUM(M)                                                                                     \
         {                                                                                                  \
             const float da = dot3(d, ax);                                                                  \
@@ -658,6 +680,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             GRT_AXIS(M, x, ivx, shx, ofx, mnx_, mxx_)                                                      \
             GRT_AXIS(M, y, ivy, shy, ofy, mny_, mxy_)                                                      \
             GRT_AXIS(M, z, ivz, shz, ofz, mnz_, mxz_)                                                      \
+            GRT_PLANES_TO_LDS                                                                              \
             if (BUNDLE) {                                                                                  \
                 GRT_POFF(M, pL, mL) GRT_POFF(M, pR, mR) GRT_POFF(M, pB, mB) GRT_POFF(M, pT, mT)            \
                 const float r_ = length3(sub3(o, oc)), ld_ = length3(d);                                   \
@@ -1192,6 +1215,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const float cx_ = lx_ + hx_, cy_ = ly_ + hy_, cz_ = lz_ + hz_;
                 const float gx_ = hx_ - lx_, gy_ = hy_ - ly_, gz_ = hz_ - lz_;
                 const float rs_ = b1.w + b1.w;
+#ifdef GRT_TILE_PLANES_LDS
+                // (shadows of the pass-level values: read back from LDS; the near side is the box's hi side where the slab factor is negative)
+                const float4 fq0 = ((const float4*)fr_lds)[0], fq1 = ((const float4*)fr_lds)[1], fq2 = ((const float4*)fr_lds)[2], fq3 = ((const float4*)fr_lds)[3];
+                const float pLx = fq0.x, pLy = fq0.y, pLz = fq0.z, pRx = fq0.w, pRy = fq1.x, pRz = fq1.y, pBx = fq1.z, pBy = fq1.w;
+                const float pBz = fq2.x, pTx = fq2.y, pTy = fq2.z, pTz = fq2.w, ivx = fq3.x, ivy = fq3.y, ivz = fq3.z;
+                const bool shx = ivx < 0.0f, shy = ivy < 0.0f, shz = ivz < 0.0f;
+#endif
 #define GRT_PSIDE(P, MP)                                                                                   \
                 ((__builtin_fmaf(P##x, cx_, __builtin_fmaf(P##y, cy_, P##z * cz_)) +                        \
                   fminf(__builtin_fmaf(fabsf(P##x), gx_, __builtin_fmaf(fabsf(P##y), gy_, fabsf(P##z) * gz_)), rs_)) >= \
