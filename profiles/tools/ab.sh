@@ -4,7 +4,7 @@ W=$1; S=$2; shift; shift
 mkdir -p gpurun_out/r4
 for rep in 1 2; do
 for L in "$@"; do
-  GRT_LIB=$PWD/gaussian-ray-tracing_amd/libgrt_hip_$L.so python bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-extra-legs 2> gpurun_out/r4/ab_$L.err | python -c "
+  GRT_LIB=$PWD/gaussian-ray-tracing_amd/libgrt_hip_$L.so python bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline --no-extra-legs --dump gpurun_out/r4/frame_${W}_$L.npy 2> gpurun_out/r4/ab_$L.err | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -12,3 +12,5 @@ for l in sys.stdin:
 "
 done
 done
+md5sum gpurun_out/r4/frame_${W}_*.npy   # the variants' frames: identical files = bit-identical frames
+rm -f gpurun_out/r4/frame_${W}_*.npy
