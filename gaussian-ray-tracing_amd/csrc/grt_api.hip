@@ -619,6 +619,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PARTS2_PCT) { c->opt_tile_parts2_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS4_PCT) { c->opt_tile_parts4_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_MESH_PARTS) { c->opt_mesh_parts = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(0, value)); }
@@ -1219,7 +1220,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         // kernels per 16x16 block (same test as launch_render)
         const uint32_t h = std::max(std::max(sc->gbvh.height, sc->n_faces ? sc->mbvh.height : 0u), 1u);
         const bool stream_kernel = uses_stream_kernel(c->opt_kernel, a.mode, h);
-        c->parts_ok = a.mode != 2 && !sc->n_faces && uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims);
+        // (mesh frames too, since round 4: a part wave of the primary stage queues its own chunk of continuation rays, <= 16 of them)
+        c->parts_ok = a.mode != 2 && (!sc->n_faces || c->opt_mesh_parts) && uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims);
         int rcf = prepare_feedback(c, a, s, stream_kernel ? a.n_blocks * 4u : a.n_blocks,
                                    uses_tile_kernel(c->opt_kernel, a.mode, h, sc->built_leaf_max, sc->gbvh.n_prims));
         if (rcf != GRT_OK) return rcf;
@@ -1238,7 +1240,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.single_look = (float)c->opt_single_look / 1024.0f;
     a.single_band = (float)c->opt_single_band / 1024.0f;
     if (sc->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
-        const size_t need = (size_t)a.n_blocks * 256;
+        // (entries of the continuation queues: one 64-entry chunk per wave of the primary stage — per 8x8 tile, and per PART of a
+        //  heavy tile when the launch order splits some)
+        const size_t need = ((size_t)a.n_blocks * 4 + parts_extra_cap(a.n_blocks * 4u)) * 64;
         if (c->wf_cap < need) {
             (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
             c->d_prec = c->d_queue = c->d_fqueue = nullptr;

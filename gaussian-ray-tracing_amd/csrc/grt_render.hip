@@ -547,6 +547,11 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
         RenderArgs b = a;
         b.order = nullptr;
         b.cost = nullptr;
+        // the most chunks a queue can hold: one per wave of the primary stage — per 8x8 tile, or per entry of a launch order that
+        // runs heavy tiles as parts (do_launch sizes the queues for it); the per-entry stages launch one thread per queue entry
+        const uint32_t max_chunks = (tile_kernel && a.order && a.n_launch) ? a.n_launch : a.n_blocks * 4u;
+        const uint32_t qblocks = (max_chunks * 64u + kBlock - 1u) / kBlock;
+        b.n_launch = max_chunks;
         float4* q[2] = {a.queue, a.queue_alt};
         uint32_t in = 0, stage = 0;
         const uint32_t rounds = tile_kernel ? std::min<uint32_t>(a.bundle_rounds, (uint32_t)kMaxBundleRounds) : 0u;
@@ -556,7 +561,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             b.queue = q[in ^ 1u]; b.qcount = a.qcount + stage + 1u;
             b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
             b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
-            hipLaunchKernelGGL(fq, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+            hipLaunchKernelGGL(fq, dim3(qblocks), dim3(kBlock), lds, stream, b);
             rc = launch_render_tile(b, count, true, 1, stream, err);          // bundles; chunks over budget -> heavy list
             if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err); // its rays: one per wave, to their end
             if (rc != GRT_OK) return rc;
@@ -567,7 +572,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
         // those rays are finished one per wave (tile kernel only: the other pipelines have no per-child BVH layout)
         b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
         b.lane_budget = tile_kernel ? a.lane_budget : 0xFFFFFFFFu;
-        hipLaunchKernelGGL(fb, dim3(a.n_blocks), dim3(kBlock), lds, stream, b);
+        hipLaunchKernelGGL(fb, dim3(qblocks), dim3(kBlock), lds, stream, b);
         if (tile_kernel) {
             RenderArgs s2 = b;
             s2.queue_in = a.fqueue; s2.heavy = nullptr; s2.hcount = b.fcount; // the retry queue itself is the list

@@ -336,6 +336,11 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 #else
 #define GRT_TILE_CHECK_FRONT(INS, K)
 #endif
+#ifdef GRT_TILE_DIAG3 /* with -DGRT_TILE_DIAG2: rounds = lanes that insert an event, stall_exits = exact tests that end in an insert */
+#define GRT_D3(INS) if (COUNT) { const uint64_t im_ = wave_ballot(INS); w.rounds += (uint32_t)__popcll(im_); w.stall_exits += im_ ? 1u : 0u; }
+#else
+#define GRT_D3(INS)
+#endif
 #define GRT_TILE_INSERT(TE_, TX_, HIT_, ID_, ALPHA_, S_, OG_, DG_, CELLB_)                                        \
                         const uint32_t id = (ID_); \
                         const uint64_t ke = mk_skey((TE_), id, 0), kx = mk_skey((TX_), id, 1); \
@@ -351,6 +356,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
                         const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); \
                         const bool ins = (k_first != kKeyInvalid) && (k_first < lost); \
                         GRT_TILE_CHECK_FRONT(ins, k_first) \
+                        GRT_D3(ins) \
                         if (wave_any(ins)) { \
                             const float alpha = (ALPHA_); \
                             const float other = (in_e && in_x) ? (TX_) : INFINITY; \
@@ -1532,7 +1538,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #endif
                         GRT_TILE_INSERT(te, tx, hit, __float_as_uint(r2.w), fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w), r0.w, o_g, d_g, __float_as_uint(r3.w))
                     }
-#ifdef GRT_TILE_DIAG2
+#if defined(GRT_TILE_DIAG2) && !defined(GRT_TILE_DIAG3)
                     if (COUNT) { w.rounds += (d2_sum + 63u) / 64u; w.stall_exits += d2_passes; }
 #endif
                     continue;
@@ -1799,7 +1805,9 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
     const bool sh = a.p.sh_degree_max > 0;
     RenderArgs b = a;
     b.heavy_role = 0;
-    const uint32_t grid = (mode == 0 && a.order && a.n_launch) ? a.n_launch : a.n_blocks * 4u; // (+ the parts of split tiles, padded)
+    // mode 0: one wave per entry of the launch order (tiles + the parts of split tiles, padded) or per tile; mode 1: one wave per
+    // chunk the queue can hold (launch_render passes it as n_launch)
+    const uint32_t grid = ((mode == 1 || a.order) && a.n_launch) ? a.n_launch : a.n_blocks * 4u;
     hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, stream, b);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -190,7 +190,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          one GPU) splits nothing.  Default 60; 0 = never.  Pixels never depend on it */,
        GRT_OPT_TILE_PARTS2_PCT = 26   /* ... above value % of the heaviest (and below the four-way threshold): TWO waves of 4x8 pixels.
                                          Default 0 = never (half a heavy tile takes as long as the whole) */,
-       GRT_OPT_TILE_PARTS_LOAD_PCT = 28 /* see GRT_OPT_TILE_PARTS4_PCT (default 75; 0 = no such condition) */ };
+       GRT_OPT_TILE_PARTS_LOAD_PCT = 28, /* see GRT_OPT_TILE_PARTS4_PCT (default 75; 0 = no such condition) */
+       GRT_OPT_MESH_PARTS = 29          /* 1 (default): the part waves also split the heavy tiles of a MESH frame's primary stage
+                                           (each part queues its own chunk of continuation rays); 0: camera-ray frames without
+                                           meshes only, as before round 4's last change */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -117,6 +117,60 @@ def test_heavy_tiles_as_part_waves_give_the_same_frame():
     tr.close(); sc.close()
 
 
+def test_part_waves_on_a_mesh_frame_give_the_same_frame():
+    """GRT_OPT_MESH_PARTS (default on): the heavy tiles of a MESH frame's primary stage run as part waves too — each part queues its
+    own chunk of continuation rays (<= 16), so the queues hold one chunk per launch-order entry.  Pure scheduling again: mirror and
+    glass sphere, full frame / window / rank tile list, thresholds that split nearly every tile, frame after frame: byte-identical
+    to the frame without part waves, per-ray counters equal, no give-up."""
+    import torch
+    for mesh_type, bounces in ((grt.MIRROR, 3), (grt.GLASS, 4)):
+        acts, p, sc, op, center = make_scene(23, 30000, 200, 136, scale_boost=0.45, mesh_type=mesh_type, max_bounces=bounces)
+        pos = (0.25 * center + 0.75 * np.float32([0, 0, 3])).astype(np.float32)
+        tr = grt.Tracer(0)
+        tr.upload(acts)
+        tr.set_meshes([grt.sphere_mesh(pos, tess_u=32, tess_v=16)])
+        tr.set_option(grt.OPT_MESH_PARTS, 0)
+        ref8, reff = tr.render(p, want_f32=True)
+        ref8, reff = ref8.clone(), reff.clone()
+        tr.set_option(grt.OPT_COUNTERS, 1)
+        tr.render(p)
+        c0 = tr.counters()
+        tr.set_option(grt.OPT_COUNTERS, 0)
+        tr.set_option(grt.OPT_MESH_PARTS, 1)
+        w8 = torch.zeros_like(ref8)
+        for v2, v4, vl in ((0, 1, 0), (1, 0, 0), (10, 40, 0), (0, 60, 75)):
+            tr.set_option(grt.OPT_TILE_PARTS2_PCT, v2)
+            tr.set_option(grt.OPT_TILE_PARTS4_PCT, v4)
+            tr.set_option(grt.OPT_TILE_PARTS_LOAD_PCT, vl)
+            for it in range(4):
+                a8, af = tr.render(p, want_f32=True)
+                assert (a8 == ref8).all() and (af == reff).all(), (mesh_type, v2, v4, it)
+            tr.set_option(grt.OPT_COUNTERS, 1)
+            tr.render(p)
+            c1 = tr.counters()
+            tr.set_option(grt.OPT_COUNTERS, 0)
+            for k in ("rays", "segments", "hit_evals"):
+                assert c1[k] == c0[k], (k, mesh_type, v2, v4)
+            assert c1["stall_exits"] == 0
+            for it in range(3):
+                w8.zero_()
+                tr.render(p, window=(24, 16, 170, 120), out_u8=w8)
+                assert (w8[16:120, 24:170] == ref8[16:120, 24:170]).all(), (mesh_type, v2, v4, it)
+            tx, ty = (200 + 31) // 32, (136 + 31) // 32
+            cnt = (tx * ty) // 2
+            buf = torch.zeros((cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+            for it in range(3):
+                tr.render_tiles(p, 32, 32, 1, 2, cnt, out_u8=buf)
+                tr.check()
+                for j in range(cnt):
+                    t = 1 + 2 * j
+                    x0, y0 = (t % tx) * 32, (t // tx) * 32
+                    h, w = min(32, 136 - y0), min(32, 200 - x0)
+                    assert (buf[j, :h, :w] == ref8[y0:y0 + h, x0:x0 + w]).all(), (mesh_type, v2, v4, it, j)
+        tr.check()
+        tr.close(); sc.close()
+
+
 def test_split_launch_with_mesh_and_tiles():
     """Big-window split launch (GRT_OPT_FEEDBACK = 5) through the wavefront pipeline and the tile entry point."""
     import torch
