@@ -455,6 +455,7 @@ __device__ __forceinline__ uint32_t cost_class_floor(uint32_t k)
     return (4u | m) << (e - 2u);
 }
 
+constexpr uint32_t kOrdBatch = 8u; // units per thread whose costs an ordering pass loads before it uses them
 __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict__ cost, uint32_t n,
                                                      uint32_t* __restrict__ order, uint32_t cap, uint32_t thr_x2,
                                                      uint32_t* __restrict__ n_heavy, uint32_t* __restrict__ zero)
@@ -463,7 +464,14 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
     const uint32_t tid = threadIdx.x;
     if (tid < 128u) hist[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
+    for (uint32_t base = 0; base < n; base += kOrdBatch * 1024u) { // (loads first, kOrdBatch per thread: see k_cost_order_parts)
+        uint32_t cv[kOrdBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) { const uint32_t i = base + k * 1024u + tid; cv[k] = (i < n) ? cost[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++)
+            if (base + k * 1024u + tid < n) atomicAdd(&hist[127u - cost_class(cost_eff(cv[k]))], 1u); // bucket 0 = heaviest
+    }
     __syncthreads();
     if (tid == 0u) {
         uint32_t acc = 0, bmed = 127u;
@@ -482,10 +490,16 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
         }
     }
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + tid;
-        if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost_eff(cost[i]))], 1u)] = i;
-        __syncthreads();
+    for (uint32_t base = 0; base < n; base += kOrdBatch * 1024u) {
+        uint32_t cv[kOrdBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) { const uint32_t i = base + k * 1024u + tid; cv[k] = (i < n) ? cost[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) { // (1024 units at a time: the units of a class stay in screen order)
+            const uint32_t i = base + k * 1024u + tid;
+            if (i < n) order[atomicAdd(&cursor[127u - cost_class(cost_eff(cv[k]))], 1u)] = i;
+            __syncthreads();
+        }
     }
     // the costs are consumed: zero them for the next frame here (one packet less behind every frame that collects costs)
     if (zero) for (uint32_t i = tid; i < n; i += 1024u) zero[i] = 0u;
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
 {
     __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
     __shared__ uint8_t ok4[128], ok2[128]; // the launch has room for this cost class's four-way / two-way parts
-    __shared__ uint32_t s_t2, s_t4, s_total, s_max;
+    __shared__ uint32_t s_t2, s_t4, s_total, s_max, s_ext, s_half;
     __shared__ unsigned long long s_sum;
     const uint32_t tid = threadIdx.x;
     if (tid < 128u) { hist[tid] = 0u; h2[tid] = 0u; h4[tid] = 0u; }
@@ -516,11 +530,25 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
     {
         uint32_t mx = 0;
         unsigned long long sm = 0;
-        for (uint32_t i = tid; i < n; i += 1024u) {
-            atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
-            const uint32_t r = cost_eff(raw[i]);
-            mx = max(mx, r);
-            sm += r;
+        // (one workgroup on one CU: a plainly written pass pays one load round trip per 1024 units; every pass of this kernel loads
+        //  kOrdBatch x 1024 units before it touches them)
+        for (uint32_t base = 0; base < n; base += kOrdBatch * 1024u) {
+            uint32_t cv[kOrdBatch], rv[kOrdBatch];
+#pragma unroll
+            for (uint32_t k = 0; k < kOrdBatch; k++) {
+                const uint32_t i = base + k * 1024u + tid;
+                cv[k] = (i < n) ? cost[i] : 0u;
+                rv[k] = (i < n) ? raw[i] : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kOrdBatch; k++) {
+                if (base + k * 1024u + tid < n) {
+                    atomicAdd(&hist[127u - cost_class(cost_eff(cv[k]))], 1u); // bucket 0 = heaviest
+                    const uint32_t r = cost_eff(rv[k]);
+                    mx = max(mx, r);
+                    sm += r;
+                }
+            }
         }
         for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sm += __shfl_xor(sm, off); }
         if ((tid & 63u) == 0u) { atomicMax(&s_max, mx); atomicAdd(&s_sum, sm); }
@@ -534,47 +562,92 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
     }
     __syncthreads();
     const uint32_t t2 = s_t2, t4 = s_t4;
-    for (uint32_t i = tid; i < n; i += 1024u) {
-        const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
-        if (r > t4) atomicAdd(&h4[b], 1u);
-        else if (r > t2) atomicAdd(&h2[b], 1u);
+    for (uint32_t base = 0; base < n; base += kOrdBatch * 1024u) {
+        uint32_t cv[kOrdBatch], rv[kOrdBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) {
+            const uint32_t i = base + k * 1024u + tid;
+            cv[k] = (i < n) ? cost[i] : 0u;
+            rv[k] = (i < n) ? raw[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) {
+            if (base + k * 1024u + tid < n) {
+                const uint32_t r = cost_eff(rv[k]), b = 127u - cost_class(cost_eff(cv[k]));
+                if (r > t4) atomicAdd(&h4[b], 1u);
+                else if (r > t2) atomicAdd(&h2[b], 1u);
+            }
+        }
     }
     __syncthreads();
-    if (tid == 0u) {
-        // room for extra_cap entries beyond one per tile: handed out heaviest class first — four-way parts, then two-way ones
-        // (a class that no longer fits four-way is tried two-way) — so that the tiles that bound the frame keep their parts
-        // whatever the lighter ones would like (deterministic: same costs, same order)
+    // Room for extra_cap entries beyond one per tile: handed out heaviest class first — four-way parts, then two-way ones (a class that
+    // no longer fits four-way is tried two-way) — so that the tiles that bound the frame keep their parts whatever the lighter ones would
+    // like (deterministic: same costs, same order).  When ALL the parts fit — nearly always: the room is a quarter of the tiles — every
+    // class gets what it asks for and 128 threads say so at once; only otherwise does one thread walk the classes in turn.  (That walk,
+    // three loops of 128 dependent LDS round trips, was 30 of this kernel's 50 us behind every frame of a moving camera.)
+    if (tid == 0u) s_ext = 0u;
+    __syncthreads();
+    if (tid < 128u) {
+        const uint32_t want = 3u * h4[tid] + h2[tid];
+        if (want) atomicAdd(&s_ext, want);
+    }
+    __syncthreads();
+    const bool two_way_ = s_t2 != 0xFFFFFFFFu; // (two-way parts are in use at all: only then may a four-way class fall back to them)
+    if (s_ext <= extra_cap) { // wave-uniform, workgroup-uniform
+        if (tid < 128u) { ok4[tid] = h4[tid] != 0u ? 1 : 0; ok2[tid] = h2[tid] != 0u ? 1 : 0; }
+    } else if (tid == 0u) {
         uint32_t extras = 0;
         for (uint32_t b = 0; b < 128u; b++) {
             const uint32_t e4 = 3u * h4[b];
             ok4[b] = (e4 != 0u && extras + e4 <= extra_cap) ? 1 : 0;
             if (ok4[b]) extras += e4;
         }
-        const bool two_way = s_t2 != 0xFFFFFFFFu; // (two-way parts are in use at all: only then may a four-way class fall back to them)
         for (uint32_t b = 0; b < 128u; b++) {
-            const uint32_t e2 = h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u);
+            const uint32_t e2 = h2[b] + ((two_way_ && !ok4[b]) ? h4[b] : 0u);
             ok2[b] = (e2 != 0u && extras + e2 <= extra_cap) ? 1 : 0;
             if (ok2[b]) extras += e2;
         }
-        uint32_t acc = 0;
-        for (uint32_t b = 0; b < 128u; b++) { // (exactly what the scatter below writes: a gap would leave a stale entry in the launch)
-            cursor[b] = acc;
-            acc += hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u) : 0u);
-        }
-        s_total = acc;
     }
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + tid;
-        if (i < n) {
-            const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
-            const bool two_way = t2 != 0xFFFFFFFFu;
-            const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
-            const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
-            const uint32_t pos = atomicAdd(&cursor[b], parts);
-            for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+    // cursor[b] = entries of the classes before b (exactly what the scatter below writes: a gap would leave a stale entry in the
+    // launch): an exclusive scan over the 128 classes by the first two waves
+    if (tid < 128u) {
+        const uint32_t b = tid;
+        const uint32_t mine = hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + ((two_way_ && !ok4[b]) ? h4[b] : 0u) : 0u);
+        uint32_t inc = mine; // inclusive scan within the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+            if ((int)(tid & 63u) >= off) inc += up;
         }
-        __syncthreads();
+        if (tid == 63u) s_half = inc; // total of classes 0..63
+        cursor[b] = inc - mine;       // (classes 64..127: + s_half below)
+        if (tid == 127u) s_total = inc;
+    }
+    __syncthreads();
+    if (tid >= 64u && tid < 128u) cursor[tid] += s_half;
+    if (tid == 0u) s_total += s_half;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kOrdBatch * 1024u) {
+        uint32_t cv[kOrdBatch], rv[kOrdBatch];
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) {
+            const uint32_t i = base + k * 1024u + tid;
+            cv[k] = (i < n) ? cost[i] : 0u;
+            rv[k] = (i < n) ? raw[i] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kOrdBatch; k++) { // (1024 units at a time, a barrier between them: the tiles of a class stay in screen order)
+            const uint32_t i = base + k * 1024u + tid;
+            if (i < n) {
+                const uint32_t r = cost_eff(rv[k]), b = 127u - cost_class(cost_eff(cv[k]));
+                const bool two_way = t2 != 0xFFFFFFFFu;
+                const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
+                const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
+                const uint32_t pos = atomicAdd(&cursor[b], parts);
+                for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+            }
+            __syncthreads();
+        }
     }
     for (uint32_t i = s_total + tid; i < n + extra_cap; i += 1024u) order[i] = kOrderPad;
     if (tid == 0u) { order[n + extra_cap] = s_total; order[n + extra_cap + 1u] = s_t4; order[n + extra_cap + 2u] = s_max; } // (diagnostics: GRT_DEBUG_LAUNCH)

@@ -652,27 +652,36 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             P##x = uni(x_ * il_); P##y = uni(y_ * il_); P##z = uni(z_ * il_);                              \
         }
 #ifdef GRT_TILE_PLANES_LDS
-#define GRT_PLANES_TO_LDS                                                                                  \
+#define GRT_PK_OF_PASS uni(fr_lds[15])
+#define GRT_PLANES_TO_LDS_(REFIT)                                                                          \
             if (lane == 0u) {                                                                              \
                 float4* q_ = (float4*)fr_lds;                                                              \
                 q_[0] = make_float4(pLx, pLy, pLz, pRx); q_[1] = make_float4(pRy, pRz, pBx, pBy);          \
-                q_[2] = make_float4(pBz, pTx, pTy, pTz); q_[3] = make_float4(ivx, ivy, ivz, 0.0f);         \
+                q_[2] = make_float4(pBz, pTx, pTy, pTz);                                                   \
+                if (!(REFIT)) q_[3] = make_float4(ivx, ivy, ivz, pk_); /* .w: the pass's width check, for its re-fits */ \
             }                                                                                              \
             wave_fence();
 #else
-#define GRT_PLANES_TO_LDS
+#define GRT_PK_OF_PASS 1.0f
+#define GRT_PLANES_TO_LDS_(REFIT)
 #endif
-#define GRT_FRUSTUM(M)                                                                                     \
+// REFIT (GRT_TILE_REFIT_PLANES, camera rays): a re-fit inside a pass narrows the four planes only.  The per-axis slab factors and
+// the width check of the pass's first fit bound a superset of the lanes that are left, so they stay valid (culling only, and the
+// largest |d| over an 8x8 tile moves in its fourth digit), and eight of a fit's twelve wave reductions are not run again.
+#define GRT_FRUSTUM(M) GRT_FRUSTUM_(M, false)
+#define GRT_FRUSTUM_(M, REFIT)                                                                             \
         {                                                                                                  \
             const float da = dot3(d, ax);                                                                  \
             const float ida = GRT_FIT_RCP1(fmaxf(da, 1e-6f));                                              \
             const float tu = dot3(d, uu) * ida, tv = dot3(d, vv) * ida;                                    \
             /* a tile wider than ~75 degrees (tiny fisheye frames) gets no culling at all: every box passes */ \
-            float mnx_, mxx_, mny_, mxy_, mnz_, mxz_, damin_, spare_;                                      \
+            float mnx_ = 0.0f, mxx_ = 0.0f, mny_ = 0.0f, mxy_ = 0.0f, mnz_ = 0.0f, mxz_ = 0.0f, damin_ = 1.0f, spare_; \
+            if (!(REFIT)) {                                                                                \
             wave_fminmax4((M) ? d.x : INFINITY, (M) ? d.x : -INFINITY, (M) ? d.y : INFINITY, (M) ? d.y : -INFINITY, mnx_, mxx_, mny_, mxy_); \
             wave_fminmax4((M) ? d.z : INFINITY, (M) ? d.z : -INFINITY, (M) ? da : 1.0f, -INFINITY, mnz_, mxz_, damin_, spare_); \
             (void)spare_;                                                                                  \
-            const float pk_ = (uni(damin_) >= 0.25f) ? 1.0f : 0.0f;                                         \
+            }                                                                                              \
+            const float pk_ = (REFIT) ? GRT_PK_OF_PASS : ((uni(damin_) >= 0.25f) ? 1.0f : 0.0f);            \
             float tu0, tu1, tv0, tv1;                                                                      \
             wave_fminmax4((M) ? tu : INFINITY, (M) ? tu : -INFINITY, (M) ? tv : INFINITY, (M) ? tv : -INFINITY, tu0, tu1, tv0, tv1); \
             tu0 = uni(tu0); tu1 = uni(tu1); tv0 = uni(tv0); tv1 = uni(tv1);                                \
@@ -683,10 +692,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             GRT_PNORM(pR, tu1 * ax.x - uu.x, tu1 * ax.y - uu.y, tu1 * ax.z - uu.z)                             \
             GRT_PNORM(pB, vv.x - tv0 * ax.x, vv.y - tv0 * ax.y, vv.z - tv0 * ax.z)                             \
             GRT_PNORM(pT, tv1 * ax.x - vv.x, tv1 * ax.y - vv.y, tv1 * ax.z - vv.z)                             \
+            if (!(REFIT)) {                                                                                \
             GRT_AXIS(M, x, ivx, shx, ofx, mnx_, mxx_)                                                      \
             GRT_AXIS(M, y, ivy, shy, ofy, mny_, mxy_)                                                      \
             GRT_AXIS(M, z, ivz, shz, ofz, mnz_, mxz_)                                                      \
-            GRT_PLANES_TO_LDS                                                                              \
+            }                                                                                              \
+            GRT_PLANES_TO_LDS_(REFIT)                                                                      \
             if (BUNDLE) {                                                                                  \
                 GRT_POFF(M, pL, mL) GRT_POFF(M, pR, mR) GRT_POFF(M, pB, mB) GRT_POFF(M, pT, mT)            \
                 const float r_ = length3(sub3(o, oc)), ld_ = length3(d);                                   \
@@ -887,7 +898,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     if (nact == 0u) F = INFINITY; // nothing left to find: the pass is over
                     done = !(F < INFINITY);
                     if (!done && (nact * 2u <= nact_ref)) { // half of them have finished: re-fit the frustum
+#if !defined(GRT_TILE_REFIT_FULL) && defined(GRT_TILE_PLANES_LDS) // (round 4: C2 -2 %, C3 / C5 -0.2 %; -DGRT_TILE_REFIT_FULL: all twelve reductions again)
+                        GRT_FRUSTUM_(act, !BUNDLE)
+#else
                         GRT_FRUSTUM(act)
+#endif
                         LIM = uni(wave_fmax(act ? ct_ : 0.0f));
                         lim_dirty = false;
                         nact_ref = nact;

@@ -183,7 +183,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_LANE_BUDGET = 20       /* whatever still bounces after the bundle rounds finishes on the per-lane traversal; a Gaussian
                                          segment over this many iterations there sends its ray to the one-ray-per-wave mode, which
                                          finishes it (default 128).  Same image for every value */,
-       GRT_OPT_TILE_PARTS4_PCT = 27   /* tile kernel, camera rays without meshes: an 8x8 tile whose cost in the previous frame exceeded
+       GRT_OPT_TILE_PARTS4_PCT = 27   /* tile kernel, camera rays (mesh frames: their primary stage, GRT_OPT_MESH_PARTS): an 8x8 tile whose cost in the previous frame exceeded
                                          value % of the heaviest tile's — and GRT_OPT_TILE_PARTS_LOAD_PCT % of the launch's total cost per
                                          resident wave — is launched as FOUR waves of 4x4 pixels (a quarter of the rays each, a narrower
                                          frustum).  A frame takes at least its longest tile; a frame bound by its total work (1080p on
