@@ -532,7 +532,7 @@ static void free_slot_state(grt_ctx* c)
 {
     (void)hipFree(c->d_erec); (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
+    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
@@ -619,6 +619,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PARTS2_PCT) { c->opt_tile_parts2_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS4_PCT) { c->opt_tile_parts4_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_ORDER_MULTI_MIN) { c->opt_order_multi_min = std::max(1, value); }
     else if (option == GRT_OPT_MESH_PARTS) { c->opt_mesh_parts = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
@@ -1054,7 +1055,8 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         *used_split = false;
         const uint32_t cap = parts_extra_cap(n_units);
         int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
-                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, s, &c->err);
+                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, c->d_ord_scratch,
+                                         (uint32_t)c->opt_order_multi_min, s, &c->err);
         if (rcp == GRT_OK) c->order_launch = n_units + cap;
         return rcp;
     }
@@ -1082,6 +1084,10 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u))); // (+ 3 diagnostic words)
+        if (!c->d_ord_scratch) { // counts and cursors of the several-workgroup ordering (grt_bvh.hip: k_ord_a); zero once, phase C keeps it so
+            CHK(c, hipMalloc(&c->d_ord_scratch, order_scratch_bytes()));
+            CHK(c, hipMemset(c->d_ord_scratch, 0, order_scratch_bytes()));
+        }
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         c->cost_cap = n_units;
     }

@@ -654,11 +654,199 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __res
     if (zero) for (uint32_t i = tid; i < n; i += 1024u) zero[i] = 0u; // (costs consumed; every thread is past its last read of them: the loop above ends in a barrier)
 }
 
+// ---- the same order made by SEVERAL workgroups (launches above kOrdMultiMin units: what is left of the one-workgroup kernel grows
+//      with the units, 1.7 us per 1024, 249 us for the 129 600 tiles of a 4K frame, behind every frame of a moving camera).  Workgroup g
+//      owns the units [g per, (g + 1) per) — a run in screen order — and the four kernels are the four phases of k_cost_order_parts:
+//      A class counts per workgroup + the heaviest tile and the total work; B the counts of the units that want to be split, with the
+//      thresholds those two give; C (one workgroup) room for the parts, the classes' first entries, every workgroup's first entry in
+//      every class (screen order within a class is kept: workgroup after workgroup, 1024 units after 1024 units); D the scatter, the
+//      padding and the zeroing of the consumed costs.  Same entries as the one-workgroup kernel writes (same classes, same codes, same
+//      room rule; inside a class both keep runs of 1024 units in order and leave the order inside a run to the atomics).
+//      Scratch (uint32): S[0] heaviest, S[2..3] total (64 bit), S[4] t2, S[5] t4, S[6] entries; S[8 + b] ok4, S[136 + b] ok2;
+//      S[kOrdCnt + (g * 3 + k) * 128 + b] counts (k = 0 all, 1 two-way, 2 four-way); S[kOrdCur + g * 128 + b] first entry.
+//      S[0], S[2], S[3] must be zero on entry: phase C leaves them so (the context zeroes the scratch once).
+constexpr uint32_t kOrdMaxGroups = 256u, kOrdCnt = 512u, kOrdCur = kOrdCnt + kOrdMaxGroups * 3u * 128u;
+__host__ __device__ inline uint32_t ord_scratch_words() { return kOrdCur + kOrdMaxGroups * 128u; }
+__device__ __forceinline__ void ord_thresholds(const uint32_t* S, uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves,
+                                               uint32_t& t2, uint32_t& t4)
+{
+    const uint64_t lmax = S[0], sum = (uint64_t)S[2] | ((uint64_t)S[3] << 32), load = sum / max(resident_waves, 1u);
+    const uint64_t floor_ = load * pct_load / 100u;
+    t4 = pct4 ? (uint32_t)min(max(lmax * pct4 / 100u, floor_), (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+    t2 = pct2 ? (uint32_t)min(max(lmax * pct2 / 100u, floor_), (uint64_t)0xFFFFFFFEu) : 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(1024) void k_ord_a(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n, uint32_t per,
+                                                uint32_t* __restrict__ S)
+{
+    __shared__ uint32_t hist[128];
+    __shared__ uint32_t s_max;
+    __shared__ unsigned long long s_sum;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x, lo = g * per, hi = min(n, lo + per);
+    if (tid < 128u) hist[tid] = 0u;
+    if (tid == 0u) { s_max = 0u; s_sum = 0ull; }
+    __syncthreads();
+    uint32_t mx = 0;
+    unsigned long long sm = 0;
+    for (uint32_t i = lo + tid; i < hi; i += 1024u) {
+        atomicAdd(&hist[127u - cost_class(cost_eff(cost[i]))], 1u); // bucket 0 = heaviest
+        const uint32_t r = cost_eff(raw[i]);
+        mx = max(mx, r);
+        sm += r;
+    }
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sm += __shfl_xor(sm, off); }
+    if ((tid & 63u) == 0u && mx) { atomicMax(&s_max, mx); atomicAdd(&s_sum, sm); }
+    __syncthreads();
+    if (tid == 0u && s_max) { atomicMax(&S[0], s_max); atomicAdd((unsigned long long*)(S + 2), s_sum); } // (one pair of global atomics per workgroup)
+    if (tid < 128u) S[kOrdCnt + (g * 3u + 0u) * 128u + tid] = hist[tid];
+}
+__global__ __launch_bounds__(1024) void k_ord_b(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n, uint32_t per,
+                                                uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* __restrict__ S)
+{
+    __shared__ uint32_t h2[128], h4[128];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x, lo = g * per, hi = min(n, lo + per);
+    if (tid < 128u) { h2[tid] = 0u; h4[tid] = 0u; }
+    uint32_t t2, t4;
+    ord_thresholds(S, pct2, pct4, pct_load, resident_waves, t2, t4);
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 1024u) {
+        const uint32_t r = cost_eff(raw[i]);
+        if (r > t4) atomicAdd(&h4[127u - cost_class(cost_eff(cost[i]))], 1u);
+        else if (r > t2) atomicAdd(&h2[127u - cost_class(cost_eff(cost[i]))], 1u);
+    }
+    __syncthreads();
+    if (tid < 128u) { S[kOrdCnt + (g * 3u + 1u) * 128u + tid] = h2[tid]; S[kOrdCnt + (g * 3u + 2u) * 128u + tid] = h4[tid]; }
+}
+__global__ __launch_bounds__(1024) void k_ord_c(uint32_t n, uint32_t groups, uint32_t extra_cap, uint32_t pct2, uint32_t pct4, uint32_t pct_load,
+                                                uint32_t resident_waves, uint32_t* __restrict__ S, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[128], h2[128], h4[128], first[128], runtot[8][128];
+    __shared__ uint8_t ok4[128], ok2[128];
+    __shared__ uint32_t s_ext, s_half, s_total;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 128u) { hist[tid] = 0u; h2[tid] = 0u; h4[tid] = 0u; }
+    if (tid == 0u) s_ext = 0u;
+    uint32_t t2, t4;
+    ord_thresholds(S, pct2, pct4, pct_load, resident_waves, t2, t4);
+    __syncthreads();
+    { // class totals over the workgroups: thread = (class, slice of the workgroups)
+        const uint32_t b = tid & 127u, sl = tid >> 7;
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        for (uint32_t g = sl; g < groups; g += 8u) {
+            a0 += S[kOrdCnt + (g * 3u + 0u) * 128u + b]; a1 += S[kOrdCnt + (g * 3u + 1u) * 128u + b]; a2 += S[kOrdCnt + (g * 3u + 2u) * 128u + b];
+        }
+        if (a0) atomicAdd(&hist[b], a0);
+        if (a1) atomicAdd(&h2[b], a1);
+        if (a2) atomicAdd(&h4[b], a2);
+    }
+    __syncthreads();
+    if (tid < 128u) {
+        const uint32_t want = 3u * h4[tid] + h2[tid];
+        if (want) atomicAdd(&s_ext, want);
+    }
+    __syncthreads();
+    const bool two_way = t2 != 0xFFFFFFFFu;
+    if (s_ext <= extra_cap) { // every class gets the parts it asks for (see k_cost_order_parts)
+        if (tid < 128u) { ok4[tid] = h4[tid] != 0u ? 1 : 0; ok2[tid] = h2[tid] != 0u ? 1 : 0; }
+    } else if (tid == 0u) {
+        uint32_t extras = 0;
+        for (uint32_t b = 0; b < 128u; b++) {
+            const uint32_t e4 = 3u * h4[b];
+            ok4[b] = (e4 != 0u && extras + e4 <= extra_cap) ? 1 : 0;
+            if (ok4[b]) extras += e4;
+        }
+        for (uint32_t b = 0; b < 128u; b++) {
+            const uint32_t e2 = h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u);
+            ok2[b] = (e2 != 0u && extras + e2 <= extra_cap) ? 1 : 0;
+            if (ok2[b]) extras += e2;
+        }
+    }
+    __syncthreads();
+    if (tid < 128u) { // first entry of every class: exclusive scan by two waves
+        const uint32_t b = tid;
+        const uint32_t mine = hist[b] + (ok4[b] ? 3u * h4[b] : 0u) + (ok2[b] ? h2[b] + ((two_way && !ok4[b]) ? h4[b] : 0u) : 0u);
+        uint32_t inc = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+            if ((int)(tid & 63u) >= off) inc += up;
+        }
+        if (tid == 63u) s_half = inc;
+        first[b] = inc - mine;
+        if (tid == 127u) s_total = inc;
+    }
+    __syncthreads();
+    if (tid >= 64u && tid < 128u) first[tid] += s_half;
+    if (tid == 0u) s_total += s_half;
+    __syncthreads();
+    { // every workgroup's first entry in every class (the entries it will write: same expression as above, its own counts): thread =
+      // (class, one of eight runs of workgroups) — the runs' totals first, then each run walks its workgroups
+        const uint32_t b = tid & 127u, sl = tid >> 7;
+        const uint32_t m4 = ok4[b] ? 3u : 0u, m2 = ok2[b] ? 1u : 0u, m42 = (ok2[b] && two_way && !ok4[b]) ? 1u : 0u;
+        const uint32_t run = (groups + 7u) / 8u, g0 = min(groups, sl * run), g1 = min(groups, g0 + run);
+        uint32_t tot = 0;
+        for (uint32_t g = g0; g < g1; g++) {
+            const uint32_t c0 = S[kOrdCnt + (g * 3u + 0u) * 128u + b], c2 = S[kOrdCnt + (g * 3u + 1u) * 128u + b], c4 = S[kOrdCnt + (g * 3u + 2u) * 128u + b];
+            tot += c0 + m4 * c4 + m2 * c2 + m42 * c4;
+        }
+        runtot[sl][b] = tot;
+        __syncthreads();
+        uint32_t cur = first[b];
+        for (uint32_t k = 0; k < sl; k++) cur += runtot[k][b];
+        for (uint32_t g = g0; g < g1; g++) {
+            const uint32_t c0 = S[kOrdCnt + (g * 3u + 0u) * 128u + b], c2 = S[kOrdCnt + (g * 3u + 1u) * 128u + b], c4 = S[kOrdCnt + (g * 3u + 2u) * 128u + b];
+            S[kOrdCur + g * 128u + b] = cur;
+            cur += c0 + m4 * c4 + m2 * c2 + m42 * c4;
+        }
+        if (tid < 128u) { S[8u + b] = ok4[b]; S[136u + b] = ok2[b]; }
+    }
+    if (tid == 0u) {
+        S[4] = t2; S[5] = t4; S[6] = s_total;
+        order[n + extra_cap] = s_total; order[n + extra_cap + 1u] = t4; order[n + extra_cap + 2u] = S[0]; // (diagnostics: GRT_DEBUG_LAUNCH)
+        S[0] = 0u; S[2] = 0u; S[3] = 0u; // consumed: the next frame's phase A starts from zero
+    }
+}
+__global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n, uint32_t per,
+                                                uint32_t extra_cap, const uint32_t* __restrict__ S, uint32_t* __restrict__ order,
+                                                uint32_t* __restrict__ zero)
+{
+    __shared__ uint32_t cursor[128];
+    __shared__ uint8_t ok4[128], ok2[128];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x, lo = g * per, hi = min(n, lo + per);
+    if (tid < 128u) { cursor[tid] = S[kOrdCur + g * 128u + tid]; ok4[tid] = (uint8_t)S[8u + tid]; ok2[tid] = (uint8_t)S[136u + tid]; }
+    const uint32_t t2 = S[4], t4 = S[5], total = S[6];
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += 1024u) { // (1024 units at a time, a barrier between them: the tiles of a class stay in screen order)
+        const uint32_t i = base + tid;
+        if (i < hi) {
+            const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
+            const bool two_way = t2 != 0xFFFFFFFFu;
+            const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
+            const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
+            const uint32_t pos = atomicAdd(&cursor[b], parts);
+            for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = total + g * 1024u + tid; i < n + extra_cap; i += gridDim.x * 1024u) order[i] = kOrderPad;
+    if (zero) for (uint32_t i = lo + tid; i < hi; i += 1024u) zero[i] = 0u; // (this workgroup's costs: its last read of them is behind the barrier above;
+                                                                            //  `cost` may be the dilated copy, `zero` is the raw array phase A-D read as `raw`)
+}
+
+uint32_t order_scratch_bytes() { return ord_scratch_words() * (uint32_t)sizeof(uint32_t); }
+
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, hipStream_t stream,
-                           std::string* err)
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
+                           uint32_t multi_min, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
+    if (d_scratch && n >= multi_min) { // several workgroups, four phases (see k_ord_a)
+        uint32_t per = 2048u; // units per workgroup: two runs of 1024
+        if ((n + per - 1u) / per > kOrdMaxGroups) per = (((n + kOrdMaxGroups - 1u) / kOrdMaxGroups) + 1023u) & ~1023u;
+        const uint32_t groups = (n + per - 1u) / per;
+        hipLaunchKernelGGL(k_ord_a, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, d_scratch);
+        hipLaunchKernelGGL(k_ord_b, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, pct2, pct4, pct_load, resident_waves, d_scratch);
+        hipLaunchKernelGGL(k_ord_c, dim3(1), dim3(1024), 0, stream, n, groups, extra_cap, pct2, pct4, pct_load, resident_waves, d_scratch, d_order);
+        hipLaunchKernelGGL(k_ord_d, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, extra_cap, (const uint32_t*)d_scratch, d_order, d_zero);
+    } else
     hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, pct2, pct4, pct_load,
                        resident_waves, d_zero);
     const hipError_t e = hipGetLastError();

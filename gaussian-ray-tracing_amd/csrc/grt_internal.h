@@ -211,9 +211,11 @@ inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, i
 int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,
                       std::string* err);
 // launch order with the heaviest tiles as 2 / 4 parts (tile kernel): n + extra_cap entries, padded with kOrderPad
+// (d_scratch: order_scratch_bytes() of device memory, zeroed once; launches of multi_min units and more are ordered by several workgroups)
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
-                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, hipStream_t stream,
-                           std::string* err);
+                           uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
+                           uint32_t multi_min, hipStream_t stream, std::string* err);
+uint32_t order_scratch_bytes();
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 // (d_zero != nullptr: that array of n cost words is zeroed once the order is made — the costs are consumed)
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
@@ -256,6 +258,7 @@ struct grt_ctx {
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
+    int opt_order_multi_min = 16384; // GRT_OPT_ORDER_MULTI_MIN: launches of this many tiles and more are ordered by several workgroups
     int opt_mesh_parts = 1;       // GRT_OPT_MESH_PARTS: heavy tiles of a MESH frame's primary stage run as part waves too
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
@@ -300,7 +303,7 @@ struct grt_ctx {
     bool have_timing = false;
     // frame-to-frame scheduling feedback (grt_api.hip: do_launch)
     int opt_feedback = 1;
-    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr;
+    uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr, *d_ord_scratch = nullptr;
     int opt_cost_radius = 4; // tiles; 0 = off
     int opt_cold_estimate = 1; // order a frame without previous-frame costs by projected particle counts
     uint32_t cost_cap = 0;

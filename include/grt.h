@@ -193,7 +193,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_TILE_PARTS_LOAD_PCT = 28, /* see GRT_OPT_TILE_PARTS4_PCT (default 75; 0 = no such condition) */
        GRT_OPT_MESH_PARTS = 29          /* 1 (default): the part waves also split the heavy tiles of a MESH frame's primary stage
                                            (each part queues its own chunk of continuation rays); 0: camera-ray frames without
-                                           meshes only, as before round 4's last change */ };
+                                           meshes only, as before round 4's last change */,
+       GRT_OPT_ORDER_MULTI_MIN = 30     /* (testing) launches of value tiles and more have their launch order made by several workgroups in
+                                           four short kernels instead of one workgroup (default 16384: from 1080p on; behind every frame of
+                                           a moving camera: 54 -> ~25 us at 1080p, 249 -> ~30 us at 4K).  Same order either way */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

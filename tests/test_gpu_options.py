@@ -171,6 +171,54 @@ def test_part_waves_on_a_mesh_frame_give_the_same_frame():
         tr.close(); sc.close()
 
 
+def test_launch_order_by_several_workgroups_gives_the_same_frame():
+    """GRT_OPT_ORDER_MULTI_MIN: from 16384 tiles on the launch order is made by several workgroups in four kernels (grt_bvh.hip: k_ord_a-d)
+    instead of one workgroup.  Forced here on a 4000-tile frame (two workgroups) and a 425-tile one (one): with every part-wave policy —
+    including more parts than the launch has room for, the one-thread room rule — frames byte-identical frame after frame, per-ray
+    counters those of whole tiles, no give-up; and a moving camera (costs of another view order the frame) likewise."""
+    import torch
+    for (w, h, n) in ((640, 400, 60000), (200, 136, 30000)):
+        acts, p, sc, op, center = make_scene(37, n, w, h, scale_boost=0.45)
+        tr = grt.Tracer(0)
+        tr.upload(acts)
+        ref8, reff = tr.render(p, want_f32=True)
+        ref8, reff = ref8.clone(), reff.clone()
+        tr.set_option(grt.OPT_COUNTERS, 1)
+        tr.render(p)
+        c0 = tr.counters()
+        tr.set_option(grt.OPT_COUNTERS, 0)
+        tr.set_option(grt.OPT_ORDER_MULTI_MIN, 1)
+        for v2, v4, vl in ((0, 60, 75), (1, 1, 0), (0, 1, 0), (10, 40, 0), (5, 5, 100)):
+            tr.set_option(grt.OPT_TILE_PARTS2_PCT, v2)
+            tr.set_option(grt.OPT_TILE_PARTS4_PCT, v4)
+            tr.set_option(grt.OPT_TILE_PARTS_LOAD_PCT, vl)
+            for it in range(4):
+                a8, af = tr.render(p, want_f32=True)
+                assert (a8 == ref8).all() and (af == reff).all(), (w, v2, v4, it)
+            tr.set_option(grt.OPT_COUNTERS, 1)
+            tr.render(p)
+            c1 = tr.counters()
+            tr.set_option(grt.OPT_COUNTERS, 0)
+            for k in ("rays", "segments", "hit_evals"):
+                assert c1[k] == c0[k], (k, w, v2, v4)
+            assert c1["stall_exits"] == 0
+        # a moving camera: every frame is ordered by the costs of the view before it (dilated), the two ways of making the order must
+        # both give the frame a fresh context gives
+        e = np.float32([0.0, 0.0, 3.0]) - center
+        for it in range(4):
+            ang = 0.03 * (it + 1)
+            eye = (float(center[0] + e[0] * np.cos(ang) + e[2] * np.sin(ang)), 0.0, float(center[2] - e[0] * np.sin(ang) + e[2] * np.cos(ang)))
+            q = grt.default_params(w, h, center, eye=eye)
+            a8, _ = tr.render(q)
+            t2 = grt.Tracer(0)
+            t2.upload(acts)
+            b8, _ = t2.render(q)
+            assert (a8 == b8).all(), (w, it)
+            t2.close()
+        tr.check()
+        tr.close(); sc.close()
+
+
 def test_split_launch_with_mesh_and_tiles():
     """Big-window split launch (GRT_OPT_FEEDBACK = 5) through the wavefront pipeline and the tile entry point."""
     import torch
