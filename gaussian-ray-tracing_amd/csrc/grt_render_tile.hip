@@ -734,7 +734,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 alive = alive && in_cone;
             }
             if (COUNT && alive && tally) c.rounds++;
+#ifndef GRT_TILE_DIAG4
             GRT_D(rounds, 1)
+#endif
             const uint64_t pass_lo = last_key; // events with key <= pass_lo were composited by an earlier pass
             const float t_lo = key_t(pass_lo);
             // Window overflow: the particle that no longer fits (the farthest of the 12 + 1) goes to the lane's BAG in
@@ -771,7 +773,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             auto do_rebalance = [&](const uint32_t nocc_, float& Ff) {
                             // ---- rebalance: the nearest kKeep entries of (frontier + bag) stay in registers, the rest
                             //      goes (back) to the bag.  Everything passes through registers: 4 bag entries per lane.
+#ifndef GRT_TILE_DIAG4
                             GRT_D(stall_exits, 1)
+#endif
                             float bl0, bl1, bl2, bl3;
                             uint32_t br0, br1, br2, br3;
 #define GRT_BLD(K)                                                                                         \
@@ -866,7 +870,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     --dsp;
                     cur = dstack[dsp];
                     cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+#ifndef GRT_TILE_DIAG4
                     GRT_D(node_visits, 1)
+#endif
                 } else {
                     float Ff = wave_min(fl);
                     Ff_cur = Ff;
@@ -989,7 +995,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             // ---- refill: one scan of the bags of the lanes in need; entry by entry, whatever is smaller
                             //      than the window's last key goes in (sorted insert) and the displaced last key takes
                             //      its place in the bag (compacted in place: position w <= i) ----
+#ifndef GRT_TILE_DIAG4
                             GRT_D(node_visits, 1)
+#endif
                             // lanes that do not need it yet but have room for four more keys come along: one scan instead
                             // of one per lane a few steps apart
                             const bool rf = need || (alive && (nb != 0u) && (GRT_RF_ROOM == kKeyInvalid) && (bagmin < lost));
@@ -1153,7 +1161,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
-                    const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs) : F * look_);
+#ifndef GRT_TILE_LOOK_MUL
+#define GRT_TILE_LOOK_MUL 1.0f
+#endif
+                    const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs * GRT_TILE_LOOK_MUL) : F * look_);
                     const bool node_near = (occm_ & ~rngm_ & wave_ballot(fl <= hz)) != 0ull;
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
@@ -1196,6 +1207,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     const uint32_t rk = lanes_below(sm);
                     const bool sel = selm && (rk < maxb);
                     const uint32_t cnt = min((uint32_t)__popcll(sm), maxb);
+#ifdef GRT_TILE_DIAG4 /* with -DGRT_TILE_DIAG: rounds = occupied frontier slots summed over the steps, node_visits / stall_exits = entries a node / leaf step took, hit_evals += bag entries */
+                    if (COUNT) { w.rounds += nocc; if (leaf_step) w.stall_exits += cnt; else w.node_visits += cnt; w.segments += 0u; }
+#endif
                     if (sel) xsel[rk] = fr;
                     fl = sel ? INFINITY : fl;
                     fr = sel ? kNoRoot : fr;
