@@ -176,6 +176,11 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 // pre-test lets through, summed over the exact tests; hit_evals = lanes that hit; node_visits = exact tests with a hit at all;
 // rounds = passes of 64 pairs if a leaf step's pre-test-positive pairs were packed perfectly; stall_exits = passes if two
 // consecutive survivors shared a pass whenever their pairs fit 64 lanes.
+#ifdef GRT_TILE_DIAG5
+#define GRT_D5(f)
+#else
+#define GRT_D5(f) GRT_D(f, 1)
+#endif
 #ifdef GRT_TILE_DIAG2
 #define GRT_TILE_DIAG
 #define GRT_D(f, n) if (COUNT) w2.f += (n);
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     while (true) {
                         const bool cl_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < lost);
                         if (!wave_any(cl_)) break;
-                        GRT_D(hit_evals, 1)
+                        GRT_D5(hit_evals)
                         const uint64_t ek = wave_umin64(cl_ ? k0 : kKeyInvalid);
                         const bool own = cl_ && (k0 == ek); // exactly one lane: a particle is tested once per pass
                         const uint64_t om = wave_ballot(own);
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
                         }
                         if (!cm_) continue;
-                        GRT_D(hit_evals, 1)
+                        GRT_D5(hit_evals)
 #ifdef GRT_TILE_ACC_LDS
                         const float4 ac_ = acc_lds[lane];
                         float T = ac_.w;
@@ -1210,6 +1215,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #ifdef GRT_TILE_DIAG4 /* with -DGRT_TILE_DIAG: rounds = occupied frontier slots summed over the steps, node_visits / stall_exits = entries a node / leaf step took, hit_evals += bag entries */
                     if (COUNT) { w.rounds += nocc; if (leaf_step) w.stall_exits += cnt; else w.node_visits += cnt; w.segments += 0u; }
 #endif
+#ifdef GRT_TILE_DIAG5 /* with -DGRT_TILE_DIAG -DGRT_TILE_DIAG4: steps by the number of lanes that still want something: rays <= 2, segments <= 4, hit_evals <= 8, proxy_tests <= 16, fetches = all steps */
+                    if (COUNT) { w.rays += nact_cur <= 2u; w.segments += nact_cur <= 4u; w.hit_evals += nact_cur <= 8u; w.proxy_tests += nact_cur <= 16u; w.fetches += 1u; }
+#endif
                     if (sel) xsel[rk] = fr;
                     fl = sel ? INFINITY : fl;
                     fr = sel ? kNoRoot : fr;
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 }
 
                 if (leaf_step) {
-                    GRT_D(fetches, 1)
+                    GRT_D5(fetches)
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
 #ifdef GRT_TILE_DIAG2
                     uint32_t d2_sum = 0, d2_prev = 0, d2_passes = 0;
@@ -1503,7 +1511,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             if (COUNT) c.fetches += BUNDLE ? 4 : 8; // wave-uniform: 64-B record (+ 64-B eye record), in 16-B units
                             act_ = alive;
                         }
-                        GRT_D(segments, 1)
+                        GRT_D5(segments)
                         if (MODE == 1) work++;
                         const f3 mu = mk3(r0.x, r0.y, r0.z);
                         m33 A;
@@ -1530,7 +1538,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         }
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
-                        GRT_D(proxy_tests, 1)
+                        GRT_D5(proxy_tests)
 #ifdef GRT_TILE_PROBE // sensitivity probes (profiles/r03_sensitivity.json): extra work per exact test, results untouched
                         {
                             float pr0_ = d_g.x, pr1_ = d_g.y;
@@ -1572,7 +1580,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #endif
                     continue;
                 }
-                GRT_D(rays, 1)
+                GRT_D5(rays)
                 // ---- node step: compaction of the wanted children into free frontier slots; what does not fit goes
                 //      to the depth-first stack ----
                 if (wm) {
