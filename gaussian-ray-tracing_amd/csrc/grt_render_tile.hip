@@ -1142,6 +1142,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const bool occ_l = fr != kNoRoot;
                 const bool rng_l = occ_l && ((fr & kLeafBit) != 0u);
                 bool leaf_step;
+                float hz_sel = -INFINITY; // (GRT_TILE_CHAIN) the look-ahead horizon of this step's selection; depth-first mode: none
+                (void)hz_sel;
                 bool dense_ = false;      // GRT_TILE_DEFER: this leaf step had more candidate ranges than it can take (nearest ones chosen)
                 float step_th = INFINITY; // ... and the box bound of the farthest range it took
                 (void)dense_; (void)step_th;
@@ -1170,6 +1172,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #define GRT_TILE_LOOK_MUL 1.0f
 #endif
                     const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs * GRT_TILE_LOOK_MUL) : F * look_);
+                    hz_sel = hz;
                     const bool node_near = (occm_ & ~rngm_ & wave_ballot(fl <= hz)) != 0ull;
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
@@ -1225,6 +1228,21 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     nref = xsel[g];
                     ngrp = cnt;
                 }
+#ifdef GRT_TILE_CHAIN
+#define GRT_STEP_DONE break     /* out of the chain loop, whose end is the end of the step loop's body */
+#else
+#define GRT_STEP_DONE continue
+#endif
+#ifdef GRT_TILE_CHAIN
+                // EXPERIMENT (round 4, profiles/r04_experiments_log.md 18): a node step whose surviving children include a FEW internal nodes
+                // within the look-ahead expands those at once — the box tests and the compaction again, without the loop top (frontier
+                // minimum, wanting lanes, compositing check) and the selection in between: on a deep tree of large overlapping boxes a
+                // tile's steps take one or two nodes each, one wide level per step.
+                uint32_t chain_depth = 0;
+                bool bail = false;
+                for (;;) {
+                uint32_t chained = 0;
+#endif
                 const uint32_t first = leaf_first(nref);
                 // (one compare per condition, made where it is voted on: a condition that arrives from another block as a
                 //  bool is voted on through a 0 / 1 register and a second compare)
@@ -1478,7 +1496,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             npr += cnt_;
                             nsl++;
                         }
-                        continue;
+                        GRT_STEP_DONE; // (the step is over: on to the next trip of the step loop)
                     }
                     while (SINGLE ? trip : (wm != 0ull)) {
                         trip = false;
@@ -1578,9 +1596,24 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 #if defined(GRT_TILE_DIAG2) && !defined(GRT_TILE_DIAG3)
                     if (COUNT) { w.rounds += (d2_sum + 63u) / 64u; w.stall_exits += d2_passes; }
 #endif
-                    continue;
+                    GRT_STEP_DONE; // (the step is over: on to the next trip of the step loop)
                 }
                 GRT_D5(rays)
+#ifdef GRT_TILE_CHAIN
+                if (MODE == 0 && wm && chain_depth < GRT_TILE_CHAIN) {
+                    const bool nxt = want && ((cref & kLeafBit) == 0u) && (lam <= hz_sel);
+                    const uint64_t nm_ = wave_ballot(nxt);
+                    const uint32_t nn_ = (uint32_t)__popcll(nm_);
+                    const uint32_t nf0_ = (uint32_t)__popcll(wave_ballot(fr == kNoRoot)), nc0_ = (uint32_t)__popcll(wm);
+                    // (their children will need slots and they free none: only while the frontier has room for all of them)
+                    if (nn_ != 0u && nn_ <= 64u / kTileWide && nf0_ >= (nc0_ - nn_) + nn_ * kTileWide + a.tile_reserve) {
+                        if (nxt) xsel[lanes_below(nm_)] = cref;
+                        want = want && !nxt;
+                        wm &= ~nm_;
+                        chained = nn_;
+                    }
+                }
+#endif
                 // ---- node step: compaction of the wanted children into free frontier slots; what does not fit goes
                 //      to the depth-first stack ----
                 if (wm) {
@@ -1599,6 +1632,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     } else {
                         if (nc > nf && dsp + (nc - nf) > kStack) { // cannot happen for the tree heights the launcher admits
                             c.stall_exits += alive ? 1u : 0u;
+#ifdef GRT_TILE_CHAIN
+                            bail = true;
+#endif
                             if (MODE == 1) { aborted = true; break; }
                             watchdog = true;
                             iters |= kCostStackBit;
@@ -1619,6 +1655,19 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         wave_fence();
                     }
                 }
+#ifdef GRT_TILE_CHAIN
+                if (!chained) break;
+                wave_fence();
+                g = lane / kTileWide;
+                j = lane % kTileWide;
+                nref = xsel[g];
+                ngrp = chained;
+                leaf_step = false;
+                chain_depth++;
+                iters++; // (a chained level is a step of the tile: the cost word, the watchdog)
+                } // chain loop
+                if (bail) break;
+#endif
             }
 #ifdef GRT_TILE_REBAL_OUT
             if (!need_rebal) break;
@@ -1774,6 +1823,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 }
 
 #undef GRT_IN_PART
+#undef GRT_STEP_DONE
 #undef GRT_TILE_INSERT
 #undef GRT_TILE_CHECK_FRONT
 #undef KS
