@@ -955,6 +955,9 @@ __global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restr
 // record i = the descendants of binary node i up to log2(kTileWide) levels down (a leaf range stays as it is, and an
 // internal descendant stops being expanded once the record is full).  Child c at [i*2W + 2c] = (lo.xyz, ref bits),
 // [i*2W + 2c + 1] = (hi.xyz, 0); unused child: ref kNoRoot with an inverted box.
+#ifndef GRT_WIDEN_BY_AREA
+#define GRT_WIDEN_BY_AREA 2
+#endif
 __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __restrict__ qn)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -972,7 +975,36 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
         r[n++] = __float_as_uint(q3.y);
     };
     push_children((uint32_t)i, box, ref, ne);
+#if GRT_WIDEN_BY_AREA
+    // (round 4, log item 19): open the internal entry with the LARGEST box first, again and again, until the record is full —
+    // up to W - 2 openings along any path instead of two rounds over all entries: the big boxes a tile's frustum is most likely to
+    // meet are opened here, once, instead of costing the traversal a step each.  = 1: only that; = 2: the two rounds first, then what is
+    // left of the record is filled that way.
+    auto fill_by_area = [&]() {
+    while (ne < W) {
+        int best = -1;
+        float ba = -1.0f;
+        for (int e = 0; e < ne; e++) {
+            if (ref[e] & kLeafBit) continue;
+            const float dx = box[e][3] - box[e][0], dy = box[e][4] - box[e][1], dz = box[e][5] - box[e][2];
+            const float ar = dx * dy + dy * dz + dz * dx;
+            if (ar > ba) { ba = ar; best = e; }
+        }
+        if (best < 0) break;
+        const uint32_t nd = ref[best];
+        for (int e = best; e + 1 < ne; e++) { // close the gap, the two children go to the end
+            for (int k = 0; k < 6; k++) box[e][k] = box[e + 1][k];
+            ref[e] = ref[e + 1];
+        }
+        ne--;
+        push_children(nd, box, ref, ne);
+    }
+    };
+    if (GRT_WIDEN_BY_AREA == 1) fill_by_area();
+    for (int round = 1; GRT_WIDEN_BY_AREA == 2 && (2 << round) <= W; round++) {
+#else
     for (int round = 1; (2 << round) <= W; round++) { // each round expands every internal entry that still fits
+#endif
         float nb[W][6];
         uint32_t nr[W];
         int nn = 0;
@@ -996,6 +1028,9 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
         }
         ne = nn;
     }
+#if GRT_WIDEN_BY_AREA
+    if (GRT_WIDEN_BY_AREA == 2) fill_by_area();
+#endif
     float4* q = qn + (size_t)i * 2 * W;
     for (int e = 0; e < W; e++) {
         if (e < ne) {

@@ -192,6 +192,28 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #define GRT_D(f, n)
 #endif
 
+// What a camera-ray tile's cost word counts besides its steps, in eighths of a step: per particle fetched, per exact test run (per insert
+// round, per compositing step: measured, no better).  Round 4: the launch order and the part-wave policy live on that word, and steps alone
+// are a poor proxy of a tile's TIME — a leaf step that carries sixteen ranges through their exact tests and a node step count the same.
+// With steps + 2/8 per particle + 12/8 per test (same-box kernel ms): C1 0.513 -> 0.472, C2 0.955 -> 0.89, a rank of eight 0.757 -> 0.737,
+// C3 -0.9 %, C5 unchanged; by instruction counts (2, 6, 5, 3): C1 0.52, C2 0.91; (2, 16, 0, 0): C1 0.516, C2 0.88; (0, 12, 0, 4): 0.50, 0.89
+// (profiles/r04_experiments_log.md 19).  -DGRT_TILE_COST_WORK=0: steps alone, as before.
+#ifndef GRT_TILE_COST_WORK
+#define GRT_TILE_COST_WORK 1
+#endif
+#ifndef GRT_COST_WF
+#define GRT_COST_WF 2u
+#endif
+#ifndef GRT_COST_WT
+#define GRT_COST_WT 12u
+#endif
+#ifndef GRT_COST_WI
+#define GRT_COST_WI 0u
+#endif
+#ifndef GRT_COST_WC
+#define GRT_COST_WC 0u
+#endif
+
 // Signed-float wave reductions: eleven per frustum fit, and a tile re-fits its frustum every time half of its wanting lanes
 // have finished.  As `fminf(v, __shfl_xor(v, off))` each was six dependent LDS round trips (ds_bpermute) and eighteen VALU
 // operations with their NaN canonicalisation; here a float goes through an order-preserving integer key (sign bit
@@ -346,6 +368,11 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 #else
 #define GRT_D3(INS)
 #endif
+#if GRT_TILE_COST_WORK
+#define GRT_COST_INS if (MODE == 0) work += GRT_COST_WI;
+#else
+#define GRT_COST_INS
+#endif
 #define GRT_TILE_INSERT(TE_, TX_, HIT_, ID_, ALPHA_, S_, OG_, DG_, CELLB_)                                        \
                         const uint32_t id = (ID_); \
                         const uint64_t ke = mk_skey((TE_), id, 0), kx = mk_skey((TX_), id, 1); \
@@ -363,6 +390,7 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
                         GRT_TILE_CHECK_FRONT(ins, k_first) \
                         GRT_D3(ins) \
                         if (wave_any(ins)) { \
+                            GRT_COST_INS \
                             const float alpha = (ALPHA_); \
                             const float other = (in_e && in_x) ? (TX_) : INFINITY; \
                             const bool full = KLAST != kKeyInvalid; \
@@ -1055,6 +1083,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         }
                         if (!cm_) continue;
                         GRT_D5(hit_evals)
+#if GRT_TILE_COST_WORK
+                        if (MODE == 0) work += GRT_COST_WC;
+#endif
 #ifdef GRT_TILE_ACC_LDS
                         const float4 ac_ = acc_lds[lane];
                         float T = ac_.w;
@@ -1321,6 +1352,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 
                 if (leaf_step) {
                     GRT_D5(fetches)
+#if GRT_TILE_COST_WORK
+                    if (MODE == 0) work += GRT_COST_WF * (uint32_t)__popcll(wm);
+#endif
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
 #ifdef GRT_TILE_DIAG2
                     uint32_t d2_sum = 0, d2_prev = 0, d2_passes = 0;
@@ -1556,6 +1590,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         }
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
+#if GRT_TILE_COST_WORK
+                        if (MODE == 0) work += GRT_COST_WT;
+#endif
                         GRT_D5(proxy_tests)
 #ifdef GRT_TILE_PROBE // sensitivity probes (profiles/r03_sensitivity.json): extra work per exact test, results untouched
                         {
@@ -1693,7 +1730,17 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
         // (unit and part code are taken from the ONE scalar that lives across the passes, the order entry)
+#if GRT_TILE_COST_WORK
+        // the cost word: steps + the weighted particle work (GRT_COST_W*, above).  The watchdog's reading of it, "steps > max_iters"
+        // (k_check_costs), stays exact: the word is kept at or below max_iters unless the watchdog fired.
+        if (!BUNDLE && a.cost && lane == 0) {
+            uint32_t cw = min((iters & kCostStepsMask) + (work >> 3), kCostStepsMask);
+            cw = watchdog ? max(cw, min(a.max_iters, kCostStepsMask - 1u) + 1u) : min(cw, a.max_iters);
+            atomicMax(&a.cost[ue & kOrderUnitMask], (iters & ~kCostStepsMask) | cw | ((ue >> 30) << kCostPartShift));
+        }
+#else
         if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[ue & kOrderUnitMask], iters | ((ue >> 30) << kCostPartShift));
+#endif
 #ifdef GRT_TILE_ACC_LDS
         if (!SINGLE) { const float4 ac_ = acc_lds[lane]; T = ac_.w; radiance = mk3(ac_.x, ac_.y, ac_.z); }
 #endif
