@@ -494,6 +494,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     // C2 -3.7 %, C3a -5.1 %, C4 -2.5 % (round 4).  -DGRT_TILE_PLANES_SGPR: the planes in scalar registers, as before.
     __shared__ __attribute__((aligned(16))) float fr_lds[16];
 #endif
+#if GRT_TILE_COST_WORK == 2
+#ifndef GRT_COST_TSHIFT
+#define GRT_COST_TSHIFT 10
+#endif
+    __shared__ uint32_t t0_lds; // the wave's start time (the last 4 B of LDS below the 16-waves-per-CU limit)
+    if (MODE == 0 && lane == 0u) t0_lds = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
@@ -1734,7 +1741,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
         // the cost word: steps + the weighted particle work (GRT_COST_W*, above).  The watchdog's reading of it, "steps > max_iters"
         // (k_check_costs), stays exact: the word is kept at or below max_iters unless the watchdog fired.
         if (!BUNDLE && a.cost && lane == 0) {
+#if GRT_TILE_COST_WORK == 2 /* EXPERIMENT: the wave's own elapsed time (s_memtime, in units of GRT_COST_TSHIFT cycles) */
+            uint32_t cw = min(((uint32_t)__builtin_amdgcn_s_memtime() - t0_lds) >> GRT_COST_TSHIFT, kCostStepsMask);
+#else
             uint32_t cw = min((iters & kCostStepsMask) + (work >> 3), kCostStepsMask);
+#endif
             cw = watchdog ? max(cw, min(a.max_iters, kCostStepsMask - 1u) + 1u) : min(cw, a.max_iters);
             atomicMax(&a.cost[ue & kOrderUnitMask], (iters & ~kCostStepsMask) | cw | ((ue >> 30) << kCostPartShift));
         }
