@@ -619,6 +619,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PARTS2_PCT) { c->opt_tile_parts2_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS4_PCT) { c->opt_tile_parts4_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_STATIC_SHARP) { c->opt_static_sharp = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_ORDER_MULTI_MIN) { c->opt_order_multi_min = std::max(1, value); }
     else if (option == GRT_OPT_MESH_PARTS) { c->opt_mesh_parts = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
@@ -1044,7 +1045,12 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
     uint32_t* d_zero = zero_costs ? c->d_cost : nullptr; // (the ordering kernel zeroes the consumed costs itself: one packet less)
     const bool split = c->opt_heavy_split == 1 || (c->opt_heavy_split == 2 && a.n_blocks <= 3072u);
     const uint32_t* cost_src = c->d_cost;
-    if (c->opt_cost_radius > 0 && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
+    // (the dilation is for a camera that MOVES: a heavy tile of the last frame is a slightly different tile of the next.  When this
+    //  frame ran with an order that was made for exactly this view — the camera stood still for two frames — the next order is made
+    //  from the tiles' own costs: a dilated map orders a standing view worse, C2 0.86 -> 0.80 ms, C3 -1.3 %; if the camera then moves,
+    //  one frame runs with an undilated order)
+    const bool dilate = c->opt_cost_radius > 0 && !(c->launch_order_matched && c->opt_static_sharp);
+    if (dilate && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
         int rcd = dilate_unit_costs(c->d_cost, c->d_cost_dil, a.nbx, a.nby, c->opt_cost_radius, s, &c->err);
         if (rcd != GRT_OK) return rcd;
         cost_src = c->d_cost_dil;

@@ -258,6 +258,7 @@ struct grt_ctx {
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
+    int opt_static_sharp = 1;     // GRT_OPT_STATIC_SHARP: a view that stood still for two frames is ordered by its tiles' own costs, not the dilated map
     int opt_order_multi_min = 16384; // GRT_OPT_ORDER_MULTI_MIN: launches of this many tiles and more are ordered by several workgroups
     int opt_mesh_parts = 1;       // GRT_OPT_MESH_PARTS: heavy tiles of a MESH frame's primary stage run as part waves too
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)

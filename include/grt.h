@@ -196,7 +196,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            meshes only, as before round 4's last change */,
        GRT_OPT_ORDER_MULTI_MIN = 30     /* (testing) launches of value tiles and more have their launch order made by several workgroups in
                                            four short kernels instead of one workgroup (default 16384: from 1080p on; behind every frame of
-                                           a moving camera: 54 -> ~25 us at 1080p, 249 -> ~30 us at 4K).  Same order either way */ };
+                                           a moving camera: 54 -> ~25 us at 1080p, 249 -> ~30 us at 4K).  Same order either way */,
+       GRT_OPT_STATIC_SHARP = 31        /* 1 (default): once a view has stood still for two frames its launch order is made from the tiles' own
+                                           costs instead of the map dilated by GRT_OPT_COST_RADIUS (which is for a camera that moves); 0: always
+                                           dilated, as before */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
