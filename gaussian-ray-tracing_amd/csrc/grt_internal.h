@@ -258,6 +258,7 @@ struct grt_ctx {
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
+    int opt_cold_parts_pct = 40;  // GRT_OPT_COLD_PARTS_PCT (with GRT_OPT_COLD_ESTIMATE = 2): four-way threshold of a cold frame, % of the heaviest estimate
     int opt_static_sharp = 1;     // GRT_OPT_STATIC_SHARP: a view that stood still for two frames is ordered by its tiles' own costs, not the dilated map
     int opt_order_multi_min = 16384; // GRT_OPT_ORDER_MULTI_MIN: launches of this many tiles and more are ordered by several workgroups
     int opt_mesh_parts = 1;       // GRT_OPT_MESH_PARTS: heavy tiles of a MESH frame's primary stage run as part waves too
@@ -306,7 +307,7 @@ struct grt_ctx {
     int opt_feedback = 1;
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr, *d_ord_scratch = nullptr;
     int opt_cost_radius = 4; // tiles; 0 = off
-    int opt_cold_estimate = 1; // order a frame without previous-frame costs by projected particle counts
+    int opt_cold_estimate = 2; // order a frame without previous-frame costs by projected particle counts
     uint32_t cost_cap = 0;
     bool cost_valid = false;
     bool order_ready = false; // d_order already holds the order for the next frame with this geometry (do_launch, post-frame)

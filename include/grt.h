@@ -158,8 +158,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          within value tiles of it (default 4; 0 = the tile's own cost) */,
        GRT_OPT_SIZE_CLASSES = 14      /* 1 (default): proxies much larger than average get subtrees of their own in the Gaussian LBVH
                                          (size class in the top Morton bits); 0: plain Morton order.  Per context; next build */,
-       GRT_OPT_COLD_ESTIMATE = 15     /* 1 (default): a frame with no previous-frame costs (first frame, new size) launches its tiles in the
-                                         order of the number of particle centres projecting into them; 0: screen order */,
+       GRT_OPT_COLD_ESTIMATE = 15     /* 1: a frame with no previous-frame costs (first frame, new size) launches its tiles in the
+                                         order of the number of particle centres projecting into them; 2 (default): and the tiles whose
+                                         estimate exceeds GRT_OPT_COLD_PARTS_PCT % of the largest (and the load condition of the part
+                                         waves) run as four part waves already in that frame; 0: screen order */,
        GRT_OPT_BUNDLE_ROUNDS = 16     /* mesh frames on the tile kernel: how many bounce iterations trace their Gaussian segment wave-
                                          cooperatively (the bounced rays of an 8x8 tile as one bundle) before the per-lane kernel
                                          finishes whatever still bounces; 0..4, default 2.  Same image for every value */,
@@ -199,7 +201,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            a moving camera: 54 -> ~25 us at 1080p, 249 -> ~30 us at 4K).  Same order either way */,
        GRT_OPT_STATIC_SHARP = 31        /* 1 (default): once a view has stood still for two frames its launch order is made from the tiles' own
                                            costs instead of the map dilated by GRT_OPT_COST_RADIUS (which is for a camera that moves); 0: always
-                                           dilated, as before */ };
+                                           dilated, as before */,
+       GRT_OPT_COLD_PARTS_PCT = 32      /* see GRT_OPT_COLD_ESTIMATE (default 40) */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

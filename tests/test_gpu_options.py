@@ -219,6 +219,35 @@ def test_launch_order_by_several_workgroups_gives_the_same_frame():
         tr.close(); sc.close()
 
 
+def test_cold_frame_with_part_waves_gives_the_same_frame():
+    """GRT_OPT_COLD_ESTIMATE = 2 (default): the FIRST frame of a launch geometry, which has no costs of a previous frame, already runs the
+    tiles with the largest estimated cost as part waves.  Pure scheduling: the first frame of a fresh context is byte-identical whatever
+    the threshold (1 %: nearly every tile split, the room rule decides), also for a window, a tile list and a fisheye frame."""
+    import torch
+    for fisheye in (False, True):
+        acts, p, sc, op, center = make_scene(41, 30000, 200, 136, scale_boost=0.45, fisheye=fisheye)
+        frames = []
+        for est, pct in ((1, 40), (2, 40), (2, 1), (2, 10), (0, 40)):
+            tr = grt.Tracer(0)
+            tr.upload(acts)
+            tr.set_option(grt.OPT_COLD_ESTIMATE, est)
+            tr.set_option(grt.OPT_COLD_PARTS_PCT, pct)
+            a8, af = tr.render(p, want_f32=True)           # cold
+            w8 = torch.zeros_like(a8)
+            tr.render(p, window=(24, 16, 170, 120), out_u8=w8)  # cold again: another launch geometry
+            tx, ty = (200 + 31) // 32, (136 + 31) // 32
+            cnt = (tx * ty) // 2
+            buf = torch.zeros((cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+            tr.render_tiles(p, 32, 32, 1, 2, cnt, out_u8=buf)   # and another
+            tr.check()
+            frames.append((a8.clone(), af.clone(), w8.clone(), buf.clone()))
+            tr.close()
+        for f in frames[1:]:
+            for x, y in zip(frames[0], f):
+                assert (x == y).all(), fisheye
+        sc.close()
+
+
 def test_split_launch_with_mesh_and_tiles():
     """Big-window split launch (GRT_OPT_FEEDBACK = 5) through the wavefront pipeline and the tile entry point."""
     import torch
