@@ -1050,7 +1050,9 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
     //  frame ran with an order that was made for exactly this view — the camera stood still for two frames — the next order is made
     //  from the tiles' own costs: a dilated map orders a standing view worse, C2 0.86 -> 0.80 ms, C3 -1.3 %; if the camera then moves,
     //  one frame runs with an undilated order)
-    const bool dilate = c->opt_cost_radius > 0 && !(c->launch_order_matched && c->opt_static_sharp);
+    //  (camera-ray frames without meshes: on C4 the undilated order costs 2 % — the stages behind the primary one take the tiles'
+    //   continuation rays in the order the primary waves finish)
+    const bool dilate = c->opt_cost_radius > 0 && !(c->launch_order_matched && c->opt_static_sharp && !scene_of(c)->n_faces);
     if (dilate && a.mode == 0 && n_units == a.n_blocks * 4u && !split) {
         int rcd = dilate_unit_costs(c->d_cost, c->d_cost_dil, a.nbx, a.nby, c->opt_cost_radius, s, &c->err);
         if (rcd != GRT_OK) return rcd;
@@ -1152,7 +1154,8 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         }
         c->order_launch = 0;
         int rc;
-        if (c->opt_cold_estimate >= 2 && c->parts_ok && a.mode == 0 && c->opt_tile_parts4_pct > 0) {
+        if (c->opt_cold_estimate >= 2 && c->parts_ok && a.mode == 0 && c->opt_tile_parts4_pct > 0 && !sc->n_faces) {
+            // (not on mesh frames: a split tile queues four thin bundles of continuation rays — C4's cold frame 3.30 -> 3.90 ms)
             // (GRT_OPT_COLD_ESTIMATE = 2, the default since round 4: the estimate also decides which tiles of the cold frame run as part
             //  waves — above GRT_OPT_COLD_PARTS_PCT % of the heaviest estimate: C1's cold frame 0.637 -> 0.553 ms, C2 1.048 -> 1.012, C3 -1.3 %)
             const uint32_t cap = parts_extra_cap(n_units);
