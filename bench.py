@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (cold frame, orbit, the other pipelining depth)")
     ap.add_argument("--kernel", type=int, default=0, help="traversal kernel variant (GRT_OPT_KERNEL)")
     ap.add_argument("--split", type=int, default=-1, help="GRT_OPT_SPLIT (piece length of the spatial splits, quarters of the typical proxy diagonal; 0 = off; -1 = library default)")
+    ap.add_argument("--leaf-max", type=int, default=0, help="GRT_OPT_LEAF_MAX before the BVH is built (0 = library default)")
     ap.add_argument("--tile", type=int, default=TILE, help="edge of the screen tiles dealt round-robin to the ranks (multiple of 16)")
     ap.add_argument("--band-abs", type=int, default=-1, help="GRT_OPT_TILE_BAND_ABS (-1 = library default)")
     ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE",
@@ -245,6 +246,8 @@ def main():
             t = grt.Tracer(local_rank)
             if args.split >= 0:
                 t.set_option(grt.OPT_SPLIT, args.split)
+            if args.leaf_max > 0:
+                t.set_option(grt.OPT_LEAF_MAX, args.leaf_max)
             t.upload(acts)
             if mesh is not None:
                 t.set_meshes([mesh])

@@ -202,9 +202,12 @@ inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
 // the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
 // (n_prims < 2^26: the tile kernel addresses the 64-B records by a 32-bit byte offset, scalar loads with an SGPR offset)
 constexpr uint32_t kTileMaxPrims = 1u << 26;
+#ifndef GRT_TILE_LEAF_LANES
+#define GRT_TILE_LEAF_LANES 4 /* lanes per leaf range in a leaf step of the tile kernel = the largest leaf it takes (8: experiment, log item 22) */
+#endif
 inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max, uint32_t n_prims)
 {
-    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= 4 &&
+    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= GRT_TILE_LEAF_LANES &&
            tile_stack_fits(stack_depth) && n_prims < kTileMaxPrims;
 }
 // per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)

@@ -48,7 +48,8 @@ namespace {
 
 constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of RenderArgs::n_blocks)
 constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kernel
-constexpr uint32_t kBatch = 16u; // nodes expanded per step (x 4 children = 64 lanes)
+constexpr uint32_t kLeafLanes = GRT_TILE_LEAF_LANES; // (grt_internal.h)
+constexpr uint32_t kBatch = 64u / kLeafLanes; // leaf ranges per leaf step (x kLeafLanes particles = 64 lanes)
 constexpr float kSweepEagerT = 0.5f; // a ready lane below this transmittance keeps a compositing sweep going on its own
 #ifndef GRT_TILE_BAG
 #define GRT_TILE_BAG 256u
@@ -1190,8 +1191,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 uint32_t g, j; // group of this lane and its child slot in the group: 4 lanes per leaf range, kTileWide per node
                 if (cur != kNoRoot) { // depth-first mode: one entry
                     leaf_step = (cur & kLeafBit) != 0u;
-                    g = leaf_step ? (lane >> 2) : (lane / kTileWide);
-                    j = leaf_step ? (lane & 3u) : (lane % kTileWide);
+                    g = leaf_step ? (lane / kLeafLanes) : (lane / kTileWide);
+                    j = leaf_step ? (lane % kLeafLanes) : (lane % kTileWide);
                     nref = cur;
                     ngrp = 1u;
                 } else {
@@ -1225,8 +1226,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     // a node step frees one slot per node and may need four: expand only what is sure to fit (at least
                     // one node: a frontier full of internal nodes overflows to the depth-first stack)
                     const uint32_t maxb = leaf_step ? kBatch : max(min(64u / kTileWide, (64u - nocc) / (kTileWide - 1u)), 1u);
-                    g = leaf_step ? (lane >> 2) : (lane / kTileWide);
-                    j = leaf_step ? (lane & 3u) : (lane % kTileWide);
+                    g = leaf_step ? (lane / kLeafLanes) : (lane / kTileWide);
+                    j = leaf_step ? (lane % kLeafLanes) : (lane % kTileWide);
                     float th = tau;
                     const uint64_t candm_ = leaf_step ? rngm_ : (occm_ & ~rngm_);
                     uint64_t sm = candm_ & wave_ballot(fl <= th);
