@@ -169,10 +169,13 @@ constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // 
 constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
 constexpr uint32_t kTileResidentWaves = 256u * 16u; // MI355X: 256 CUs x 16 waves of the camera-ray kernel (128 VGPRs, < 10 KB of LDS)
 constexpr uint32_t kCostPartShift = 27u, kCostStepsMask = 0x07FFFFFFu;
+#ifndef GRT_PART_EFF_STEP
+#define GRT_PART_EFF_STEP 1u /* a split tile's cost word is scaled back by (8 + code x this) / 8: 9/8 for halves, 10/8 for quarters */
+#endif
 __host__ __device__ inline uint32_t cost_eff(uint32_t c)
 {
     const uint32_t code = (c >> kCostPartShift) & 3u, steps = c & kCostStepsMask;
-    return code ? (uint32_t)(((uint64_t)steps * (8u + code)) >> 3) : steps;
+    return code ? (uint32_t)(((uint64_t)steps * (8u + code * GRT_PART_EFF_STEP)) >> 3) : steps;
 }
 constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
 constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
