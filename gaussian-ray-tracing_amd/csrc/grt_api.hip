@@ -778,7 +778,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     }
     if (rc == GRT_OK)
         rc = build_lbvh(d_owner ? d_plo : d_lo, d_owner ? d_phi : d_hi, d_owner ? n_pieces : n, (uint32_t)c->opt_leaf_max, true, false,
-                        c->opt_size_classes, &c->gbvh, c->stream, &c->err);
+                        c->opt_size_classes, &c->gbvh, c->stream, &c->err, d_owner != nullptr);
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
         if (c->cap_rec < m) {

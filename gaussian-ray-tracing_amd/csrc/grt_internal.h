@@ -55,7 +55,8 @@ struct DevBvh {
 // keep_levels: keep the per-node refit order so that refit_lbvh can re-fit the boxes of the SAME hierarchy later.
 // size_classes: Gaussian BVH only (GRT_OPT_SIZE_CLASSES of the context that builds).
 int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
-               int size_classes, DevBvh* out, hipStream_t stream, std::string* err);
+               int size_classes, DevBvh* out, hipStream_t stream, std::string* err, bool widen_area_only = false);
+// (widen_area_only: the 8-wide records open the largest box first throughout — trees with pieces; grt_bvh.hip: k_qwiden)
 // Re-fit every reachable node's boxes to new primitive boxes (same primitives, same order, same hierarchy): what a
 // gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
 int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
