@@ -245,7 +245,7 @@ struct grt_ctx {
     int opt_kernel = 0;
     int opt_leaf_max = 4;
     int opt_swizzle = 2;
-    int opt_tile_ready = 24, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = 24, opt_tile_prio = 0; // band / look in 1/1024
+    int opt_tile_ready = 24, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = -1 /* auto: 16, trees with pieces 24 */, opt_tile_prio = 0; // band / look in 1/1024
     int opt_size_classes = 1;
     int opt_band_abs = 512;       // GRT_OPT_TILE_BAND_ABS: that floor in 1/64 of the geometric-mean proxy diagonal
     float gm_diag = 0.f;          // geometric mean of the proxies' box diagonals (grt_build_bvh)

@@ -152,7 +152,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_TILE_READY_MIN = 8     /* lanes that must hold a final event for a compositing sweep to start or go on (fewer when few lanes still want anything), 1..64 (24) */,
        GRT_OPT_TILE_BAND = 9          /* particles within value/1024 of the front distance are tested as one batch (64) */,
        GRT_OPT_TILE_LOOKAHEAD = 10    /* nodes within value/1024 of the nearest node's distance are expanded together (64) */,
-       GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (24) */,
+       GRT_OPT_TILE_RESERVE = 11      /* with fewer than value free frontier slots the nearest leaf ranges are tested first (-1 = default: 16, trees with pieces 24) */,
        GRT_OPT_TILE_PRIO_DIV = 12     /* the heaviest 1/value of the tiles (by last frame's cost) run at raised wave priority; 0 = off */,
        GRT_OPT_COST_RADIUS = 13       /* scheduling feedback under a moving camera: a tile's cost is the largest of last frame's costs
                                          within value tiles of it (default 4; 0 = the tile's own cost) */,

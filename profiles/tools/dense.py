@@ -8,7 +8,9 @@ W, H = 1920, 1080
 h, edges = np.histogramdd(acts["pos"], bins=48, range=[(-1.5, 1.5)] * 3)
 order = np.argsort(h.ravel())[::-1]
 tr = grt.Tracer(0)
-if len(sys.argv) > 1: tr.set_option(grt.OPT_SPLIT, int(sys.argv[1]))
+if len(sys.argv) > 1 and int(sys.argv[1]) >= 0: tr.set_option(grt.OPT_SPLIT, int(sys.argv[1]))
+for kv in sys.argv[2:]:  # further arguments: option=value
+    k_, v_ = kv.split("="); tr.set_option(int(k_), int(v_))
 tr.upload(acts)
 out = []
 for rank in (0, 1, 2):

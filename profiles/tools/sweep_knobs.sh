@@ -10,7 +10,7 @@ for l in sys.stdin:
         j=json.loads(l); print('$W', '$L', 'kernel', j['kernel_ms'], 'ms/frame', j['ms_per_step'])
 "
 }
-for W in C3 C2 C5; do
+for W in C2 C1 C3 C5; do
   run $W default
   for v in 12 16 32 48; do run $W ready_min=$v --opt 8=$v; done
   for v in 32 96 128 192; do run $W band=$v --opt 9=$v; done
