@@ -363,31 +363,39 @@ __global__ void k_gather_tris(const float* __restrict__ verts, const uint32_t* _
 // order the launch of a frame that has no previous-frame costs (first frame, camera cut, new size): dense tiles first.
 // The projection inverts getRay / getFishEyeRay (shaders/tracer.cuh:115-165) for a point instead of a pixel; it never
 // touches a pixel value.
+// the pixel a world point projects to (the inverse of getRay / getFishEyeRay, shaders/tracer.cuh:115-165); false: behind the camera,
+// outside the fisheye circle or outside the image
+__device__ __forceinline__ bool project_point(const grt_params& p, f3 x, float& fx, float& fy)
+{
+    const f3 v = sub3(x, mk3(p.eye[0], p.eye[1], p.eye[2]));
+    const f3 U = mk3(p.U[0], p.U[1], p.U[2]), V = mk3(p.V[0], p.V[1], p.V[2]), W = mk3(p.W[0], p.W[1], p.W[2]);
+    // components of v in the (-U, -V, W) basis the ray generators use (the three are mutually orthogonal)
+    const float su = -dot3(v, U) / fmaxf(dot3(U, U), 1e-30f), sv = -dot3(v, V) / fmaxf(dot3(V, V), 1e-30f),
+                sw = dot3(v, W) / fmaxf(dot3(W, W), 1e-30f);
+    float dx, dy;
+    if (!p.mode_fisheye) {
+        if (!(sw > 1e-6f)) return false; // behind the camera
+        dx = su / sw; dy = sv / sw;
+    } else {
+        const float len = sqrtf(su * su + sv * sv + sw * sw);
+        if (!(len > 0.0f)) return false;
+        const float ct = fminf(fmaxf(sw / len, -1.0f), 1.0f);
+        const float r = sqrtf(2.0f) * sqrtf(fmaxf(0.5f * (1.0f - ct), 0.0f)); // sqrt(2) sin(theta / 2)
+        const float rho = sqrtf(su * su + sv * sv);
+        if (!(r <= 1.0f) || !(rho > 0.0f)) return false;
+        dx = r * su / rho; dy = r * sv / rho;
+    }
+    fx = (dx + 1.0f) * 0.5f * (float)p.width; fy = (dy + 1.0f) * 0.5f * (float)p.height;
+    return fx >= 0.0f && fy >= 0.0f && fx < (float)p.width && fy < (float)p.height;
+}
+
 __global__ void k_estimate_costs(const float* __restrict__ pos, uint32_t n, uint32_t stride, const RenderArgs a,
                                  uint32_t* __restrict__ cost)
 {
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) * stride; // a sample of the particles is enough for an ORDER
     if (i >= n) return;
-    const f3 v = sub3(mk3(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]), mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]));
-    const f3 U = mk3(a.p.U[0], a.p.U[1], a.p.U[2]), V = mk3(a.p.V[0], a.p.V[1], a.p.V[2]), W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
-    // components of v in the (-U, -V, W) basis the ray generators use (the three are mutually orthogonal)
-    const float su = -dot3(v, U) / fmaxf(dot3(U, U), 1e-30f), sv = -dot3(v, V) / fmaxf(dot3(V, V), 1e-30f),
-                sw = dot3(v, W) / fmaxf(dot3(W, W), 1e-30f);
-    float dx, dy;
-    if (!a.p.mode_fisheye) {
-        if (!(sw > 1e-6f)) return; // behind the camera
-        dx = su / sw; dy = sv / sw;
-    } else {
-        const float len = sqrtf(su * su + sv * sv + sw * sw);
-        if (!(len > 0.0f)) return;
-        const float ct = fminf(fmaxf(sw / len, -1.0f), 1.0f);
-        const float r = sqrtf(2.0f) * sqrtf(fmaxf(0.5f * (1.0f - ct), 0.0f)); // sqrt(2) sin(theta / 2)
-        const float rho = sqrtf(su * su + sv * sv);
-        if (!(r <= 1.0f) || !(rho > 0.0f)) return;
-        dx = r * su / rho; dy = r * sv / rho;
-    }
-    const float fx = (dx + 1.0f) * 0.5f * (float)a.p.width, fy = (dy + 1.0f) * 0.5f * (float)a.p.height;
-    if (!(fx >= 0.0f && fy >= 0.0f && fx < (float)a.p.width && fy < (float)a.p.height)) return;
+    float fx, fy;
+    if (!project_point(a.p, mk3(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]), fx, fy)) return;
     const uint32_t px = (uint32_t)fx, py = (uint32_t)fy;
     uint32_t blk, lx, ly;
     if (a.mode == 0) {
