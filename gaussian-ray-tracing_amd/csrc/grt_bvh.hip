@@ -456,9 +456,9 @@ __device__ __forceinline__ uint32_t cost_class_floor(uint32_t k)
 }
 
 constexpr uint32_t kOrdBatch = 8u; // units per thread whose costs an ordering pass loads before it uses them
-__global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict__ cost, uint32_t n,
+__global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* cost, uint32_t n,
                                                      uint32_t* __restrict__ order, uint32_t cap, uint32_t thr_x2,
-                                                     uint32_t* __restrict__ n_heavy, uint32_t* __restrict__ zero)
+                                                     uint32_t* __restrict__ n_heavy, uint32_t* zero) // (`zero` may alias `cost`: neither is restrict)
 {
     __shared__ uint32_t hist[128], cursor[128];
     const uint32_t tid = threadIdx.x;
@@ -515,9 +515,9 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* __restrict_
 // whole).  With a frame that is bound by its total work (1080p on one GPU, 4K) nothing is split.  Entry = unit | part << 28 |
 // code << 30; the parts of a tile are consecutive; everything past the last entry is kOrderPad.  The launch has room for extra_cap
 // entries beyond one per tile: they go to the heaviest cost classes first.
-__global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n,
+__global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* cost, const uint32_t* raw, uint32_t n,
                                                            uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t pct2, uint32_t pct4,
-                                                           uint32_t pct_load, uint32_t resident_waves, uint32_t* __restrict__ zero)
+                                                           uint32_t pct_load, uint32_t resident_waves, uint32_t* zero) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
 {
     __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
     __shared__ uint8_t ok4[128], ok2[128]; // the launch has room for this cost class's four-way / two-way parts
@@ -804,9 +804,9 @@ __global__ __launch_bounds__(1024) void k_ord_c(uint32_t n, uint32_t groups, uin
         S[0] = 0u; S[2] = 0u; S[3] = 0u; // consumed: the next frame's phase A starts from zero
     }
 }
-__global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ raw, uint32_t n, uint32_t per,
+__global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint32_t* raw, uint32_t n, uint32_t per,
                                                 uint32_t extra_cap, const uint32_t* __restrict__ S, uint32_t* __restrict__ order,
-                                                uint32_t* __restrict__ zero)
+                                                uint32_t* zero) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
 {
     __shared__ uint32_t cursor[128];
     __shared__ uint8_t ok4[128], ok2[128];
@@ -955,9 +955,6 @@ __global__ void k_widen(const float4* __restrict__ nodes, int m, float4* __restr
 // record i = the descendants of binary node i up to log2(kTileWide) levels down (a leaf range stays as it is, and an
 // internal descendant stops being expanded once the record is full).  Child c at [i*2W + 2c] = (lo.xyz, ref bits),
 // [i*2W + 2c + 1] = (hi.xyz, 0); unused child: ref kNoRoot with an inverted box.
-#ifndef GRT_WIDEN_BY_AREA
-#define GRT_WIDEN_BY_AREA 2
-#endif
 __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __restrict__ qn, int area_only)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -975,11 +972,10 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
         r[n++] = __float_as_uint(q3.y);
     };
     push_children((uint32_t)i, box, ref, ne);
-#if GRT_WIDEN_BY_AREA
     // (round 4, log item 19): open the internal entry with the LARGEST box first, again and again, until the record is full —
     // up to W - 2 openings along any path instead of two rounds over all entries: the big boxes a tile's frustum is most likely to
-    // meet are opened here, once, instead of costing the traversal a step each.  = 1: only that; = 2: the two rounds first, then what is
-    // left of the record is filled that way.
+    // meet are opened here, once, instead of costing the traversal a step each.  Default: the two rounds first, then what is left
+    // of the record is filled that way.
     auto fill_by_area = [&]() {
     while (ne < W) {
         int best = -1;
@@ -1002,11 +998,8 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
     };
     // (area_only: trees with pieces — large overlapping boxes, a depth-serial traversal: the needle scene C3a -4.3 % with the largest box
     //  opened first throughout, -0.4 % with the fill; the compact scenes lose with it: C2 +14 %)
-    if (GRT_WIDEN_BY_AREA == 1 || area_only) fill_by_area();
-    for (int round = 1; GRT_WIDEN_BY_AREA == 2 && !area_only && (2 << round) <= W; round++) {
-#else
-    for (int round = 1; (2 << round) <= W; round++) { // each round expands every internal entry that still fits
-#endif
+    if (area_only) fill_by_area();
+    for (int round = 1; !area_only && (2 << round) <= W; round++) { // each round expands every internal entry that still fits
         float nb[W][6];
         uint32_t nr[W];
         int nn = 0;
@@ -1030,9 +1023,7 @@ __global__ void k_qwiden(const float4* __restrict__ nodes, int m, float4* __rest
         }
         ne = nn;
     }
-#if GRT_WIDEN_BY_AREA
-    if (GRT_WIDEN_BY_AREA == 2 && !area_only) fill_by_area();
-#endif
+    if (!area_only) fill_by_area();
     float4* q = qn + (size_t)i * 2 * W;
     for (int e = 0; e < W; e++) {
         if (e < ne) {

@@ -108,83 +108,16 @@ __device__ __forceinline__ void slab_project(f3 v, float a[10])
     a[8] = px - qy; a[9] = px + qy;
 }
 
-// GRT_SLAB_PK (EXPERIMENT, round 4, default 0 = off): how much of the exact test runs on packed f32 pairs (1 = the slab loop: near and
-// far bound as the halves of one register pair, v_pk_fma_f32 / v_pk_mul_f32, 11 instead of 15 instructions per slab; 2 = and the
-// projections of the direction; 3 = and the two quotients).  Every level computes the same values by the same roundings — the
-// frames are bit-identical — and every level is SLOWER: C3 +2.3 % / +4.0 % / +3.9 %, C5 +2.6 %, C3a +2.6 % at level 2.  A packed f32
-// instruction holds the SIMD for two passes (profiles/r03_valu_calib.json: 3.1 cycles per v_pk_fma_f32 at 4 waves per SIMD against
-// 1.95 per independent v_fma_f32) and draws hazard s_nop when its result feeds the next one: "the frame is its instruction count"
-//  counts packed instructions double.
-#ifndef GRT_SLAB_PK
-#define GRT_SLAB_PK 0
-#endif
-typedef float grt_v2f __attribute__((ext_vector_type(2)));
-#if defined(__HIP_DEVICE_COMPILE__)
-// slab_project on register pairs (x, y) — 2 packed + 2 plain multiplies, 6 packed adds instead of 6 + 12; same products, same sums
-__device__ __forceinline__ void slab_project_pk(f3 v, float a[10])
-{
-    const grt_v2f xy = {v.x, v.y};
-    const grt_v2f pxy = xy * (grt_v2f){kIcoP, kIcoP};
-    const grt_v2f qxy = xy * (grt_v2f){kIcoQ, kIcoQ};
-    const float pz = kIcoP * v.z, qz = kIcoQ * v.z;
-    const grt_v2f a01 = (grt_v2f){pxy.y, pxy.y} + (grt_v2f){-qz, qz};
-    const grt_v2f a23 = (grt_v2f){qxy.x, qxy.x} + (grt_v2f){-pz, pz};
-    const grt_v2f a89 = (grt_v2f){pxy.x, pxy.x} + (grt_v2f){-qxy.y, qxy.y};
-    const grt_v2f pm = (grt_v2f){v.x, v.x} + (grt_v2f){v.y, -v.y}; // (x + y, x - y)
-    const grt_v2f a45 = pm - (grt_v2f){v.z, v.z};
-    const grt_v2f a76 = pm + (grt_v2f){v.z, v.z};
-    a[0] = a01.x; a[1] = a01.y; a[2] = a23.x; a[3] = a23.y;
-    a[4] = a45.x; a[5] = a45.y; a[6] = a76.y; a[7] = a76.x;
-    a[8] = a89.x; a[9] = a89.y;
-}
-// (n.x / d.x, n.y / d.y), IEEE: the compiler's own expansion of an f32 division (v_div_scale x 2, v_rcp, three refinement steps,
-// v_div_fmas, v_div_fixup; f32 denormals are on, so no mode switch) with the six multiply-adds in the middle done for both
-// quotients at once
-__device__ __forceinline__ grt_v2f div_pk(grt_v2f n, grt_v2f d)
-{
-    bool c0, c1, u0, u1;
-    const grt_v2f ds = {__builtin_amdgcn_div_scalef(n.x, d.x, false, &u0), __builtin_amdgcn_div_scalef(n.y, d.y, false, &u1)};
-    const grt_v2f ns = {__builtin_amdgcn_div_scalef(n.x, d.x, true, &c0), __builtin_amdgcn_div_scalef(n.y, d.y, true, &c1)};
-    grt_v2f r = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
-    const grt_v2f one = {1.0f, 1.0f};
-    const grt_v2f e0 = __builtin_elementwise_fma(-ds, r, one);
-    r = __builtin_elementwise_fma(e0, r, r);
-    grt_v2f q = ns * r;
-    const grt_v2f e1 = __builtin_elementwise_fma(-ds, q, ns);
-    q = __builtin_elementwise_fma(e1, r, q);
-    const grt_v2f e2 = __builtin_elementwise_fma(-ds, q, ns);
-    const float q0 = __builtin_amdgcn_div_fmasf(e2.x, r.x, q.x, c0), q1 = __builtin_amdgcn_div_fmasf(e2.y, r.y, q.y, c1);
-    return (grt_v2f){__builtin_amdgcn_div_fixupf(q0, d.x, n.x), __builtin_amdgcn_div_fixupf(q1, d.y, n.y)};
-}
-#endif
-
 // exact proxy test; same operation sequence as oracle/grt_oracle.c:proxy_slabs
 // a[] = slab_project(o_g), formed by the caller (per lane, or once per eye and particle: k_eye_records)
-// EARLY > 0 (wave-cooperative callers, experiment GRT_TILE_EARLY_OUT): after slab EARLY the wave asks whether ANY lane of
-// `lanes` can still hit — entry <= exit so far, as the cross product nn fd <= fn nd with a 1e-5 relative slack (the entry bound
-// only grows and the exit bound only shrinks from here on, so a lane that is out by more than the slack stays out) — and
-// returns false for all of them when none can: the result is what the full test returns, six slabs earlier.
-template <int EARLY = 0>
-__device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float s, float& t_entry, float& t_exit, bool lanes = true)
+__device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float s, float& t_entry, float& t_exit)
 {
     float b[10];
-#if GRT_SLAB_PK >= 2 && defined(__HIP_DEVICE_COMPILE__)
-    slab_project_pk(d_g, b);
-#else
     slab_project(d_g, b);
-#endif
     const float s3 = s * kSqrt3;
-#if GRT_SLAB_PK == 0 || !defined(__HIP_DEVICE_COMPILE__)
     float nn = 0.0f, nd = 0.0f, fn = 0.0f, fd = 0.0f;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-        if (EARLY > 0 && i == EARLY) {
-            const float l_ = nn * fd, r_ = fn * nd;
-            if (__builtin_amdgcn_ballot_w64(lanes && !(l_ > r_ + 1e-5f * (fabsf(l_) + fabsf(r_)) + 1e-37f)) == 0ull) {
-                t_entry = 1.0f; t_exit = 0.0f;
-                return false;
-            }
-        }
         const float h = (i >= 4 && i <= 7) ? s3 : s;
         // a with the sign of b folded in: the sign BIT of b (so b = -0 counts as negative; its slab then sits at -+1e30 times
         // something on either reading and bounds nothing), two VALU operations instead of a compare, a move and a select
@@ -201,40 +134,6 @@ __device__ __forceinline__ bool proxy_slabs_pre(const float a[10], f3 d_g, float
     }
     t_entry = nn / nd;
     t_exit = fn / fd;
-#else
-    grt_v2f num = {0.0f, 0.0f}, den = {0.0f, 0.0f}; // (near, far) numerators and denominators of the bounds so far
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        if (EARLY > 0 && i == EARLY) {
-            const float l_ = num.x * den.y, r_ = num.y * den.x;
-            if (__builtin_amdgcn_ballot_w64(lanes && !(l_ > r_ + 1e-5f * (fabsf(l_) + fabsf(r_)) + 1e-37f)) == 0ull) {
-                t_entry = 1.0f; t_exit = 0.0f;
-                return false;
-            }
-        }
-        const float h = (i >= 4 && i <= 7) ? s3 : s;
-        // (GRT_SLAB_PK) the sign bit of b as a factor +-1: a sg is a with b's sign folded in, exactly, so that the numerators are
-        // fma(-a, sg, -+h) = -(a' + h) and h - a' rounded once, bit for bit
-        const float sg = __builtin_copysignf(1.0f, b[i]);
-        const float bp = fmaxf(fabsf(b[i]), 1e-30f);
-        const grt_v2f c = __builtin_elementwise_fma((grt_v2f){-a[i], -a[i]}, (grt_v2f){sg, sg}, (grt_v2f){-h, h}); // (-(a' + h), h - a')
-        if (i == 0) {
-            num = c; den = (grt_v2f){bp, bp};
-        } else {
-            const grt_v2f l = c * den, r = num * (grt_v2f){bp, bp};
-            if (l.x > r.x) { num.x = c.x; den.x = bp; }
-            if (l.y < r.y) { num.y = c.y; den.y = bp; }
-        }
-    }
-#if GRT_SLAB_PK >= 3
-    const grt_v2f t_ = div_pk(num, den);
-    t_entry = t_.x;
-    t_exit = t_.y;
-#else
-    t_entry = num.x / den.x;
-    t_exit = num.y / den.y;
-#endif
-#endif
     return t_entry <= t_exit;
 }
 __device__ __forceinline__ bool proxy_slabs(f3 o_g, f3 d_g, float s, float& t_entry, float& t_exit)

@@ -21,10 +21,7 @@ __host__ __device__ inline uint32_t leaf_first(uint32_t ref) { return ref & kLea
 __host__ __device__ inline uint32_t leaf_count(uint32_t ref) { return ((ref >> 28) & 7u) + 1u; }
 constexpr uint32_t kNoRoot = 0xFFFFFFFFu;
 // children per node in the tile kernel's view of the tree (DevBvh::qnodes): 4, 8 or 16
-#ifndef GRT_TILE_WIDE
-#define GRT_TILE_WIDE 8
-#endif
-constexpr uint32_t kTileWide = GRT_TILE_WIDE;
+constexpr uint32_t kTileWide = 8u; // (4-wide: C3 +6.5 %, 16-wide: +9-14 %, measured in rounds 2 and 4)
 
 // LBVH in traversal layout.  One 64-B record (4 x float4) per INTERNAL node holding the boxes of
 // its two children, so a node fetch decides both descents:
@@ -170,13 +167,10 @@ constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // 
 constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
 constexpr uint32_t kTileResidentWaves = 256u * 16u; // MI355X: 256 CUs x 16 waves of the camera-ray kernel (128 VGPRs, < 10 KB of LDS)
 constexpr uint32_t kCostPartShift = 27u, kCostStepsMask = 0x07FFFFFFu;
-#ifndef GRT_PART_EFF_STEP
-#define GRT_PART_EFF_STEP 1u /* a split tile's cost word is scaled back by (8 + code x this) / 8: 9/8 for halves, 10/8 for quarters */
-#endif
 __host__ __device__ inline uint32_t cost_eff(uint32_t c)
 {
     const uint32_t code = (c >> kCostPartShift) & 3u, steps = c & kCostStepsMask;
-    return code ? (uint32_t)(((uint64_t)steps * (8u + code * GRT_PART_EFF_STEP)) >> 3) : steps;
+    return code ? (uint32_t)(((uint64_t)steps * (8u + code)) >> 3) : steps;
 }
 constexpr uint32_t kTileMaxItersDefault = 1u << 21; // a heavy C3 tile takes ~2000 steps
 constexpr uint32_t kTileStack = 288u;               // depth-first overflow stack of the tile kernel (entries)
@@ -188,10 +182,7 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the retry queue, [2R+2 .. 3R+1] the draw
 // counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
 constexpr int kWfCounters = 3 * kMaxBundleRounds + 3;
-#ifndef GRT_TILE_OVF
-#define GRT_TILE_OVF 96
-#endif
-constexpr uint32_t kTileOvfEntries = GRT_TILE_OVF; // per-lane capacity of a window-overflow bag
+constexpr uint32_t kTileOvfEntries = 96u; // per-lane capacity of a window-overflow bag
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
 // GRT_OPT_KERNEL values: 0 auto (tile kernel where it applies, else streaming), 1 per-lane, 2 round-based wave,
 // 3 streaming, 4 big-window streaming (testing), 5 tile
@@ -206,12 +197,10 @@ inline bool uses_stream_kernel(int variant, uint32_t mode, uint32_t stack_depth)
 // the tile kernel expands leaf ranges of <= 4 proxies, four lanes per range
 // (n_prims < 2^26: the tile kernel addresses the 64-B records by a 32-bit byte offset, scalar loads with an SGPR offset)
 constexpr uint32_t kTileMaxPrims = 1u << 26;
-#ifndef GRT_TILE_LEAF_LANES
-#define GRT_TILE_LEAF_LANES 4 /* lanes per leaf range in a leaf step of the tile kernel = the largest leaf it takes (8: experiment, log item 22) */
-#endif
+constexpr int kTileLeafMax = 4; // lanes per leaf range in a leaf step of the tile kernel = the largest leaf it takes (8: measured, mixed: r04 log item 22)
 inline bool uses_tile_kernel(int variant, uint32_t mode, uint32_t stack_depth, int built_leaf_max, uint32_t n_prims)
 {
-    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= GRT_TILE_LEAF_LANES &&
+    return uses_stream_kernel(variant, mode, stack_depth) && (variant == 0 || variant == 5) && built_leaf_max <= kTileLeafMax &&
            tile_stack_fits(stack_depth) && n_prims < kTileMaxPrims;
 }
 // per-tile cost map dilated by `radius` tiles (full-frame / window launches of the wave-per-tile kernels)

@@ -48,40 +48,31 @@ namespace {
 
 constexpr int kBlock = 256; // threads of a 16x16 screen block (the unit of RenderArgs::n_blocks)
 constexpr int kWG = 64;     // one wave per workgroup, as in the streaming kernel
-constexpr uint32_t kLeafLanes = GRT_TILE_LEAF_LANES; // (grt_internal.h)
+constexpr uint32_t kLeafLanes = (uint32_t)kTileLeafMax; // lanes per leaf range in a leaf step (grt_internal.h)
 constexpr uint32_t kBatch = 64u / kLeafLanes; // leaf ranges per leaf step (x kLeafLanes particles = 64 lanes)
 constexpr float kSweepEagerT = 0.5f; // a ready lane below this transmittance keeps a compositing sweep going on its own
-#ifndef GRT_TILE_BAG
-#define GRT_TILE_BAG 256u
-#endif
-constexpr uint32_t kBag = GRT_TILE_BAG;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
+constexpr uint32_t kBag = 256u;  // far frontier entries parked in LDS (4 per lane when they are rebalanced)
 constexpr uint32_t kStack = kTileStack; // depth-first overflow stack (only when the LDS bag is full too; guarded; the launcher
                                   // admits only trees it can hold: tile_stack_fits).  LDS per wave must stay <= 10 KB:
                                   // 10304 B gave 15 waves per CU instead of 16 and cost 4 %
 constexpr uint32_t kKeep = 40u; // frontier entries kept in registers by a rebalance (the nearest ones)
 constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a lane's column of an overflow chunk holds; the
                                            // capacity in use is a.ovf_entries (<= kOvf; smaller only in tests)
+constexpr int kBisect = 18;          // most bisection steps of a nearest-k selection (4 / 6 at least)
+constexpr uint32_t kPruneRoom = 32u; // a window bag with less room than this is pruned between steps
+constexpr int kWavesPerSimd = 4;     // waves per SIMD the camera-ray and bundle kernels are compiled for (128 VGPRs)
+// The cost word of a camera-ray tile counts, besides its steps, 2/8 of a step per particle fetched and 12/8 per exact test run: the
+// launch order and the part-wave policy live on that word, and steps alone are a poor proxy of a tile's TIME (a leaf step that carries
+// sixteen ranges through their exact tests and a node step count the same).  Same-box kernel ms with it: C1 0.513 -> 0.472, C2 0.955 ->
+// 0.89, a rank of eight 0.757 -> 0.737; other weightings and the wave's own clock: profiles/r04_experiments_log.md 19.
+constexpr uint32_t kCostFetch = 2u, kCostTest = 12u;
 
-#ifndef GRT_TILE_WAVES
-#define GRT_TILE_WAVES 4
-#endif
+// The only compile-time variants of this file: GRT_TILE_KS = 8 with GRT_TILE_SINGLE_TU (grt_render_tile_single.hip: the one-ray-per-wave
+// mode as a translation unit of its own, 3 waves per SIMD), GRT_TILE_DIAG (wave-level trip counts in the counters), GRT_TILE_CHECK
+// (invariant checks), GRT_MARKS (section marks in the assembly, for the ISA budget).  tests/test_isa_lint.py compiles each of them.
+// The switches of experiments that lost live on as profiles/tools/r04_experiments_removed.patch.
 #ifndef GRT_TILE_WAVES2
-#define GRT_TILE_WAVES2 2 /* ... the one-ray-per-wave kernel (MODE 2; 19 KB of LDS per wave at 12 keys: 8 waves per CU) */
-#endif
-#ifndef GRT_TILE_WAVES1
-#define GRT_TILE_WAVES1 GRT_TILE_WAVES /* ... the bundle kernel (MODE 1) */
-#endif
-#ifndef GRT_TILE_WAVES0
-#define GRT_TILE_WAVES0 GRT_TILE_WAVES /* waves per SIMD the camera-ray kernel without meshes is compiled for */
-#endif
-#ifndef GRT_BISECT
-#define GRT_BISECT 18 /* most bisection steps of a nearest-k selection (4 / 6 at least) */
-#endif
-#ifndef GRT_PRUNE_ROOM
-#define GRT_PRUNE_ROOM 32u /* a bag with less room than this is pruned between steps */
-#endif
-#ifndef GRT_RF_ROOM
-#define GRT_RF_ROOM k8 /* a lane with room above this slot joins a refill scan it does not need yet */
+#define GRT_TILE_WAVES2 2 /* waves per SIMD of the one-ray-per-wave kernel (MODE 2; 19 KB of LDS per wave at 12 keys: 8 waves per CU) */
 #endif
 #ifndef GRT_TILE_KS
 #define GRT_TILE_KS 12 /* keys of a lane's sorted window: 12, or 8 */
@@ -91,6 +82,7 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #if GRT_TILE_KS == 12
 #define KLAST k11
 #define KPRESS k9 /* a lane holding >= KS-2 keys asks for compositing before the next insert */
+#define KROOM k8  /* a lane with room above this slot joins a refill scan it does not need yet */
 #define GRT_KEYS_DECL                                                                                      \
     uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,     \
              k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid, k8 = kKeyInvalid, k9 = kKeyInvalid,     \
@@ -99,8 +91,7 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 #elif GRT_TILE_KS == 8
 #define KLAST k7
 #define KPRESS k5
-#undef GRT_RF_ROOM
-#define GRT_RF_ROOM k4
+#define KROOM k4
 #define GRT_KEYS_DECL                                                                                      \
     uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,     \
              k5 = kKeyInvalid, k6 = kKeyInvalid, k7 = kKeyInvalid;
@@ -115,105 +106,29 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 
 // Diagnostic build (make EXTRA=-DGRT_TILE_DIAG, never shipped; counters on): the counters hold WAVE-level trip counts —
 // rays: node steps, segments: particles fetched, hit_evals: compositing steps, rounds: passes, node_visits: depth-first
-// pops, proxy_tests: exact tests executed, rec_fetches: leaf steps, stall_exits: frontier rebalances.
+// pops + window refills, proxy_tests: exact tests executed, rec_fetches: leaf steps, stall_exits: frontier rebalances.
 // Checking build (make EXTRA=-DGRT_TILE_CHECK, never shipped): stall_exits counts violated invariants (an event turning
 // up below the front: +1 per lane; frontier entries not conserved by a rebalance: +1000 per lane) and, when a float
 // frame is rendered, row 0 of it receives the (t, 2 id + exit, T) log of the events lane GRT_TILE_CHECK_LANE composites.
-// Hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp) in the frustum fit instead of the correctly
-// rounded divisions and square roots (a tile re-fits its frustum every time half of its wanting lanes have finished).  Bit 0:
-// the per-lane 1 / (d . axis) — (tu, tv) move by 1.2e-7 relative, the bounds are widened by 1e-4; bit 1: the plane normals —
-// unit to 1.2e-7, against the 2e-5 slack of the plane tests; bit 2: the per-axis slab bounds — (1 - 1e-6) / max|d| within
-// 2.4e-7, still a lower bound.  Culling only: frames are bit-identical.  7 (all three) ships since round 4 (C3 -1.3 %); 0 = the
-// exact arithmetic.  This is the build that failed in round 3 — a register-allocator defect, not numerics:
-// profiles/r04_experiments_log.md, csrc/hipcc_via_asm.py.
-#ifndef GRT_FIT_APPROX
-#define GRT_FIT_APPROX 7
-#endif
-#if GRT_FIT_APPROX & 1
-#define GRT_FIT_RCP1(x) __builtin_amdgcn_rcpf(x)
-#else
-#define GRT_FIT_RCP1(x) (1.0f / (x))
-#endif
-#if GRT_FIT_APPROX & 2
-#define GRT_FIT_NRM(p, x) ((p) * __builtin_amdgcn_rsqf(x))
-#else
-#define GRT_FIT_NRM(p, x) ((p) / sqrtf(x))
-#endif
-#if GRT_FIT_APPROX & 4
-#define GRT_FIT_DIV4(a, x) ((a) * __builtin_amdgcn_rcpf(x))
-#else
-#define GRT_FIT_DIV4(a, x) ((a) / (x))
-#endif
-// EXPERIMENT (-DGRT_TILE_COLD_HINTS): mark the rare wave-uniform blocks (frontier rebalance, depth-first pops, window-bag
-// pruning and refills, bag spills, later-pass culls) as unlikely, so that block placement moves them out of the hot loop's text.
-#ifdef GRT_TILE_COLD_HINTS
-#define GRT_RARE(x) __builtin_expect(!!(x), 0)
-#else
-#define GRT_RARE(x) (x)
-#endif
 #ifndef GRT_TILE_CHECK_LANE
 #define GRT_TILE_CHECK_LANE 0u
 #endif
-#ifdef GRT_TILE_PROBE
-#ifndef GRT_PROBE_VDEP
-#define GRT_PROBE_VDEP 0
-#endif
-#ifndef GRT_PROBE_VIND
-#define GRT_PROBE_VIND 0
-#endif
-#ifndef GRT_PROBE_SALU
-#define GRT_PROBE_SALU 0
-#endif
-#ifndef GRT_PROBE_TRIP
-#define GRT_PROBE_TRIP 0
-#endif
-#ifndef GRT_PROBE_NOP
-#define GRT_PROBE_NOP 0
-#endif
-#endif
-// Pair-statistics build (make EXTRA=-DGRT_TILE_DIAG2, never shipped; counters on; profiles/tools/diag2.py): what packing the
-// exact test into (ray, particle) pairs could save, measured before it is built.  Per wave: segments = particles fetched,
-// proxy_tests = exact tests run, rec_fetches - 2 node_visits = leaf steps (as in the diagnostic build); rays = lanes the sphere
-// pre-test lets through, summed over the exact tests; hit_evals = lanes that hit; node_visits = exact tests with a hit at all;
-// rounds = passes of 64 pairs if a leaf step's pre-test-positive pairs were packed perfectly; stall_exits = passes if two
-// consecutive survivors shared a pass whenever their pairs fit 64 lanes.
-#ifdef GRT_TILE_DIAG5
-#define GRT_D5(f)
-#else
-#define GRT_D5(f) GRT_D(f, 1)
-#endif
-#ifdef GRT_TILE_DIAG2
-#define GRT_TILE_DIAG
-#define GRT_D(f, n) if (COUNT) w2.f += (n);
-#elif defined(GRT_TILE_DIAG)
+#if defined(GRT_TILE_DIAG)
 #define GRT_D(f, n) if (COUNT) w.f += (n);
 #elif defined(GRT_MARKS)
 #define GRT_D(f, n) asm volatile("; GRT_MARK " #f);
 #else
 #define GRT_D(f, n)
 #endif
-
-// What a camera-ray tile's cost word counts besides its steps, in eighths of a step: per particle fetched, per exact test run (per insert
-// round, per compositing step: measured, no better).  Round 4: the launch order and the part-wave policy live on that word, and steps alone
-// are a poor proxy of a tile's TIME — a leaf step that carries sixteen ranges through their exact tests and a node step count the same.
-// With steps + 2/8 per particle + 12/8 per test (same-box kernel ms): C1 0.513 -> 0.472, C2 0.955 -> 0.89, a rank of eight 0.757 -> 0.737,
-// C3 -0.9 %, C5 unchanged; by instruction counts (2, 6, 5, 3): C1 0.52, C2 0.91; (2, 16, 0, 0): C1 0.516, C2 0.88; (0, 12, 0, 4): 0.50, 0.89
-// (profiles/r04_experiments_log.md 19).  -DGRT_TILE_COST_WORK=0: steps alone, as before.
-#ifndef GRT_TILE_COST_WORK
-#define GRT_TILE_COST_WORK 1
-#endif
-#ifndef GRT_COST_WF
-#define GRT_COST_WF 2u
-#endif
-#ifndef GRT_COST_WT
-#define GRT_COST_WT 12u
-#endif
-#ifndef GRT_COST_WI
-#define GRT_COST_WI 0u
-#endif
-#ifndef GRT_COST_WC
-#define GRT_COST_WC 0u
-#endif
+// The frustum fit uses the hardware reciprocal / reciprocal square root (v_rcp_f32 / v_rsq_f32, 1 ulp) instead of correctly rounded
+// divisions and square roots (a tile re-fits its frustum every time half of its wanting lanes have finished): the per-lane
+// 1 / (d . axis) — (tu, tv) move by 1.2e-7 relative, the bounds are widened by 1e-4; the plane normals — unit to 1.2e-7, against the
+// 2e-5 slack of the plane tests; the per-axis slab bounds — (1 - 1e-6) / max|d| within 2.4e-7, still a lower bound.  Culling only:
+// frames are bit-identical (C3 -1.3 %, round 4).  This is the build that failed in round 3 — a register-allocator defect, not
+// numerics: profiles/r04_experiments_log.md 1, csrc/hipcc_via_asm.py.
+#define GRT_FIT_RCP1(x) __builtin_amdgcn_rcpf(x)
+#define GRT_FIT_NRM(p, x) ((p) * __builtin_amdgcn_rsqf(x))
+#define GRT_FIT_DIV4(a, x) ((a) * __builtin_amdgcn_rcpf(x))
 
 // Signed-float wave reductions: eleven per frustum fit, and a tile re-fits its frustum every time half of its wanting lanes
 // have finished.  As `fminf(v, __shfl_xor(v, off))` each was six dependent LDS round trips (ds_bpermute) and eighteen VALU
@@ -289,7 +204,7 @@ __device__ __forceinline__ void wave_fence()
 // hundreds of overlapping proxies (all their exit events pending at once) needs a pass per dozen events.  Pruning instead
 // keeps the cut-off at about the bag's median, ~50 events ahead, for one scan of the bag (+ five of a 16-entry sample).
 // Lanes with `doit` prune; bp = the lane's column of its tile's chunk (entry i at bp[i * 64]).  Called between steps
-// (few values live there), as soon as a bag has fewer than GRT_PRUNE_ROOM free entries.
+// (few values live there), as soon as a bag has fewer than kPruneRoom free entries.
 __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, uint64_t& bagmin, uint64_t& lost)
 {
     const uint32_t n = doit ? nb : 0u;
@@ -351,91 +266,11 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
     }
 }
 
-// One surviving particle's events into the lanes' windows (lanes = rays): keys of the entry / exit events inside the lane's
-// interval, piece ownership, the response (computed only when some lane inserts), window overflow into the lane's bag, sorted
-// insert.  A macro because two loops share it: the exact test with lanes = rays (every mode) and, in the GRT_TILE_PAIRS
-// experiment, the insert phase behind a pass over (ray, particle) pairs.  (> last_key, not just > pass_lo, with pieces: a particle
-// that entered the tree as several pieces is met once per piece the tile crosses, with the same keys; float compares first: te / tx
-// may be negative or NaN, the unsigned key compares assume t > 0; alpha does not depend on the hit distance, shaders/tracer.cuh:
-// 354-357; window full: the largest pending key leaves — into the lane's bag in global memory, or for good: the lane is then lossy
-// beyond it.)
 #ifdef GRT_TILE_CHECK
 #define GRT_TILE_CHECK_FRONT(INS, K) if ((INS) && key_t(K) < F) c.stall_exits++; /* finality violated: an event below the front turned up late */
 #else
 #define GRT_TILE_CHECK_FRONT(INS, K)
 #endif
-#ifdef GRT_TILE_DIAG3 /* with -DGRT_TILE_DIAG2: rounds = lanes that insert an event, stall_exits = exact tests that end in an insert */
-#define GRT_D3(INS) if (COUNT) { const uint64_t im_ = wave_ballot(INS); w.rounds += (uint32_t)__popcll(im_); w.stall_exits += im_ ? 1u : 0u; }
-#else
-#define GRT_D3(INS)
-#endif
-#if GRT_TILE_COST_WORK
-#define GRT_COST_INS if (MODE == 0) work += GRT_COST_WI;
-#else
-#define GRT_COST_INS
-#endif
-#define GRT_TILE_INSERT(TE_, TX_, HIT_, ID_, ALPHA_, S_, OG_, DG_, CELLB_)                                        \
-                        const uint32_t id = (ID_); \
-                        const uint64_t ke = mk_skey((TE_), id, 0), kx = mk_skey((TX_), id, 1); \
-                        const uint64_t seen_ = PIECES ? last_key : pass_lo; \
-                        bool in_e = (HIT_) && ((TE_) >= t_lo) && ((TE_) < t_hi) && (ke > seen_); \
-                        bool in_x = (HIT_) && ((TX_) >= t_lo) && ((TX_) < t_hi) && (kx > seen_); \
-                        const uint32_t cellb = PIECES ? (CELLB_) : 0u; \
-                        if (PIECES && cellb) { \
-                            const bool own_ = piece_owns(cellb, (S_), (OG_), (DG_), in_e ? (TE_) : (TX_)); \
-                            in_e = in_e && own_; \
-                            in_x = in_x && own_; \
-                        } \
-                        const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid); \
-                        const bool ins = (k_first != kKeyInvalid) && (k_first < lost); \
-                        GRT_TILE_CHECK_FRONT(ins, k_first) \
-                        GRT_D3(ins) \
-                        if (wave_any(ins)) { \
-                            GRT_COST_INS \
-                            const float alpha = (ALPHA_); \
-                            const float other = (in_e && in_x) ? (TX_) : INFINITY; \
-                            const bool full = KLAST != kKeyInvalid; \
-                            const bool take = ins && (!full || k_first < KLAST); \
-                            const bool drop = ins && full; \
-                            const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask); \
-                            if (GRT_RARE(wave_any(drop))) { \
-                                if (!SINGLE && chunk == kNoRoot) { \
-                                    uint32_t ch = 0; \
-                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u); \
-                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch); \
-                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u); \
-                                } \
-                                const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask); \
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost); \
-                                if (to_bag) { \
-                                    const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha; \
-                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] = \
-                                        make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a); \
-                                    nb++; \
-                                    bagmin = (dk < bagmin) ? dk : bagmin; \
-                                } \
-                                const bool gone = drop && !to_bag; \
-                                lost = (gone && (dk < lost)) ? dk : lost; \
-                                if (SINGLE) lost = wave_umin64(lost); \
-                                else bags = true; \
-                                if (wave_any(gone)) lim_dirty = true; \
-                            } \
-                            KLAST = (take && full) ? kKeyInvalid : KLAST; \
-                            pmask = take ? (pmask | (1u << cell)) : pmask; \
-                            if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; } \
-                            if (SINGLE && take) { \
-                                f3 L; \
-                                if (!SH) { \
-                                    const float4 cc = a.color0[id]; \
-                                    L = mk3(cc.x, cc.y, cc.z); \
-                                } else { \
-                                    L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max); \
-                                } \
-                                PL_COL(cell, 0) = L.x; PL_COL(cell, 1) = L.y; PL_COL(cell, 2) = L.z; \
-                            } \
-                            SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid) \
-                        }
-
 // BUNDLE = true (stage 3 of the mesh wavefront pipeline): the wave's 64 rays are one chunk of the continuation queue —
 // the rays of one 8x8 tile after their bounce, each with its own origin.  The frustum planes get offsets (each plane is
 // pushed out to the outermost origin), the distance bounds are taken about the first ray's origin and loosened by the
@@ -458,50 +293,21 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
 // instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
 template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
-__global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT_TILE_WAVES1 : (MODE == 0 && !MESH ? GRT_TILE_WAVES0 : GRT_TILE_WAVES))) void k_render_tile(const RenderArgs a)
+__global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) void k_render_tile(const RenderArgs a)
 {
     constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
-    // EXPERIMENT (-DGRT_TILE_PAIRS, never shipped; profiles/r04_experiments_log.md item 4): the exact test of camera rays on compacted
-    // (ray, particle) pairs — a leaf step's survivors are pre-tested as ever (lanes = rays, scalar operands), the lanes the pre-test
-    // lets through become a pair list, <= 4 survivors / <= 64 pairs at a time are slab-tested with lanes = PAIRS (the ray's direction
-    // by ds_bpermute, the two records from an LDS copy), the results go back through LDS and the inserts run with lanes = rays again.
-#ifdef GRT_TILE_PAIRS
-    constexpr bool PAIRS = (MODE == 0) && !PIECES;
-#else
-    constexpr bool PAIRS = false;
-#endif
     const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
     const uint32_t n_in = BUNDLE ? (SINGLE ? *a.hcount : *a.qcount_in) : 0u; // chunks of the queue / rays of the heavy list
     const uint32_t lane = threadIdx.x;
     __shared__ float pl_other[KS * kWG], pl_alpha[KS * kWG];
     __shared__ float pl_col[SINGLE ? 3 * KS * kWG : 1]; // MODE 2: the event's radiance, fetched by the lane that inserted it
     (void)pl_col;
-#ifdef GRT_TILE_ACC_LDS
-    __shared__ float4 acc_lds[SINGLE ? 1 : kWG]; // EXPERIMENT: (radiance, T) of every lane live here between compositing steps
-#endif
-    __shared__ __attribute__((aligned(16))) float pr_stg[PAIRS ? 4 * 32 : 4]; // PAIRS: record (16 dwords) + eye record (16 dwords) of <= 4 staged survivors (read as float4)
-    __shared__ uint32_t pr_list[PAIRS ? 64 : 1];  // PAIRS: pair -> ray lane | staging slot << 6
-    __shared__ float pr_res[PAIRS ? 3 * 64 : 1];  // PAIRS: entry t (+inf: no hit), exit t, alpha of every pair
-    __shared__ uint2 pr_mask[PAIRS ? 4 : 1];      // PAIRS: the staged survivors' pre-test lane masks
-    (void)pr_stg; (void)pr_list; (void)pr_res; (void)pr_mask;
-#ifndef GRT_TILE_PLANES_SGPR
-#define GRT_TILE_PLANES_LDS 1
-#endif
-#ifdef GRT_TILE_PLANES_LDS
     // The frustum's twelve plane components and three slab factors live in LDS (64 B: what was left under the 16-waves-per-CU
     // limit) instead of 21 SGPRs that are alive across every loop of the kernel; the step reads them back by four broadcast
     // ds_read_b128.  The kernel spilled 22 SGPRs to VGPR lanes; it spills 6 now, and the v_readlane / v_writelane inside loops — whose
     // static count predicts the frame across builds (profiles/r04_experiments_log.md 10, 11) — went from 171 to 141: C3 -4.5 %, C5 -4.4 %,
-    // C2 -3.7 %, C3a -5.1 %, C4 -2.5 % (round 4).  -DGRT_TILE_PLANES_SGPR: the planes in scalar registers, as before.
+    // C2 -3.7 %, C3a -5.1 %, C4 -2.5 % (round 4).
     __shared__ __attribute__((aligned(16))) float fr_lds[16];
-#endif
-#if GRT_TILE_COST_WORK == 2
-#ifndef GRT_COST_TSHIFT
-#define GRT_COST_TSHIFT 10
-#endif
-    __shared__ uint32_t t0_lds; // the wave's start time (the last 4 B of LDS below the 16-waves-per-CU limit)
-    if (MODE == 0 && lane == 0u) t0_lds = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
@@ -517,9 +323,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     if (BUNDLE && unit_s >= n_in) break; // wave-uniform
     Cnt c, w;
     (void)w;
-#ifdef GRT_TILE_DIAG2
-    Cnt w2;
-#endif
     // camera rays: an entry of the launch order may name a PART of a heavy tile (grt_internal.h: kOrderUnitMask; grt_bvh.hip:
     // k_cost_order_parts) — the wave then traces the tile's upper / lower 4 rows, or one of its 4x4 quadrants, and the other
     // lanes carry no ray; entries past the last one are padding
@@ -630,9 +433,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
     const float minT = a.p.minTransmittance;
     float T = 1.0f - density_in; // the payload's density carries over from segment to segment (shaders/tracer.cuh:331)
     f3 radiance = mk3(0.0f, 0.0f, 0.0f);
-#ifdef GRT_TILE_ACC_LDS
-    if (!SINGLE) acc_lds[lane] = make_float4(0.0f, 0.0f, 0.0f, T);
-#endif
     if (COUNT && have_ray && tally) c.segments++;
     const uint64_t raym = wave_ballot(have_ray);
     if (a.root_ref != kNoRoot && raym) {
@@ -692,7 +492,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             const float il_ = GRT_FIT_NRM(pk_, __builtin_fmaf(x_, x_, __builtin_fmaf(y_, y_, z_ * z_))); \
             P##x = uni(x_ * il_); P##y = uni(y_ * il_); P##z = uni(z_ * il_);                              \
         }
-#ifdef GRT_TILE_PLANES_LDS
 #define GRT_PK_OF_PASS uni(fr_lds[15])
 #define GRT_PLANES_TO_LDS_(REFIT)                                                                          \
             if (lane == 0u) {                                                                              \
@@ -702,11 +501,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 if (!(REFIT)) q_[3] = make_float4(ivx, ivy, ivz, pk_); /* .w: the pass's width check, for its re-fits */ \
             }                                                                                              \
             wave_fence();
-#else
-#define GRT_PK_OF_PASS 1.0f
-#define GRT_PLANES_TO_LDS_(REFIT)
-#endif
-// REFIT (GRT_TILE_REFIT_PLANES, camera rays): a re-fit inside a pass narrows the four planes only.  The per-axis slab factors and
+// REFIT (camera rays): a re-fit inside a pass narrows the four planes only.  The per-axis slab factors and
 // the width check of the pass's first fit bound a superset of the lanes that are left, so they stay valid (culling only, and the
 // largest |d| over an 8x8 tile moves in its fourth digit), and eight of a fit's twelve wave reductions are not run again.
 #define GRT_FRUSTUM(M) GRT_FRUSTUM_(M, false)
@@ -775,9 +570,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 alive = alive && in_cone;
             }
             if (COUNT && alive && tally) c.rounds++;
-#ifndef GRT_TILE_DIAG4
             GRT_D(rounds, 1)
-#endif
             const uint64_t pass_lo = last_key; // events with key <= pass_lo were composited by an earlier pass
             const float t_lo = key_t(pass_lo);
             // Window overflow: the particle that no longer fits (the farthest of the 12 + 1) goes to the lane's BAG in
@@ -809,14 +602,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             float F = 0.0f;
             float Ff_cur = 0.0f; // minimum of the register part of the frontier (loop top)
             bool done = false;
-            // (the rebalance of frontier + LDS bag, as a lambda: called where the step loop finds it due — or, in the GRT_TILE_REBAL_OUT
-            //  experiment, behind the loop, which is then re-entered)
+            // (the rebalance of frontier + LDS bag, as a lambda: called where the step loop finds it due)
             auto do_rebalance = [&](const uint32_t nocc_, float& Ff) {
                             // ---- rebalance: the nearest kKeep entries of (frontier + bag) stay in registers, the rest
                             //      goes (back) to the bag.  Everything passes through registers: 4 bag entries per lane.
-#ifndef GRT_TILE_DIAG4
                             GRT_D(stall_exits, 1)
-#endif
                             float bl0, bl1, bl2, bl3;
                             uint32_t br0, br1, br2, br3;
 #define GRT_BLD(K)                                                                                         \
@@ -836,9 +626,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                             f2 = (bl1 < INFINITY) ? bl1 : 0.0f, f3 = (bl2 < INFINITY) ? bl2 : 0.0f,
                                             f4 = (bl3 < INFINITY) ? bl3 : 0.0f;
                                 float lo_ = lo0, hi_ = uni(wave_fmax(fmaxf(fmaxf(f0, f1), fmaxf(f2, fmaxf(f3, f4)))));
-                                // (up to GRT_BISECT steps, until at least half of kKeep qualify: in a dense cluster hundreds of
+                                // (up to kBisect steps, until at least half of kKeep qualify: in a dense cluster hundreds of
                                 //  entries lie within 1e-3 of each other while the farthest one stretches the interval)
-                                for (int it = 0; it < GRT_BISECT; it++) {
+                                for (int it = 0; it < kBisect; it++) {
                                     const float mid = 0.5f * (lo_ + hi_);
                                     const uint32_t n_ = (uint32_t)__popcll(wave_ballot(fl <= mid)) + (uint32_t)__popcll(wave_ballot(bl0 <= mid)) +
                                                         (uint32_t)__popcll(wave_ballot(bl1 <= mid)) + (uint32_t)__popcll(wave_ballot(bl2 <= mid)) +
@@ -898,42 +688,25 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             Ff = wave_min(fl);
                             Ff_cur = Ff;
             };
-#ifdef GRT_TILE_REBAL_OUT
-            bool need_rebal = false, skip_rebal = false;
-            for (;;) {
-#endif
 
             while (true) {
                 uint32_t cur = kNoRoot; // entry taken off the overflow stack (depth-first mode; F stays as it is)
                 if (dsp && !wave_any(alive)) dsp = 0; // every lane is done: nothing on the stack matters any more
                 const bool dfs = dsp != 0u;
-                if (GRT_RARE(dfs)) {
+                if (dfs) {
                     --dsp;
                     cur = dstack[dsp];
                     cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-#ifndef GRT_TILE_DIAG4
                     GRT_D(node_visits, 1)
-#endif
                 } else {
                     float Ff = wave_min(fl);
                     Ff_cur = Ff;
-#ifdef GRT_TILE_REBAL_OUT
-                    const bool rb_check_ = nbag != 0u && !skip_rebal;
-                    skip_rebal = false;
-                    if (GRT_RARE(rb_check_)) {
-#else
-                    if (GRT_RARE(nbag)) {
-#endif
+                    if (nbag) {
                         const uint32_t nocc_ = (uint32_t)__popcll(wave_ballot(fr != kNoRoot));
                         // (everything but one entry may end up in the bag: only when frontier + bag fit it)
                         if ((rebal || !(Ff < INFINITY) || ((Fbag <= Ff + Ff * look_) && (nocc_ + 8u <= kKeep))) &&
                             (nocc_ + nbag <= kBag)) {
-#ifdef GRT_TILE_REBAL_OUT
-                            need_rebal = true; // EXPERIMENT: leave the step loop; the rebalance runs outside it (below) and the loop is re-entered
-                            break;
-#else
                             do_rebalance(nocc_, Ff);
-#endif
                         }
                     }
                     F = fminf(Ff, Fbag);
@@ -945,11 +718,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     if (nact == 0u) F = INFINITY; // nothing left to find: the pass is over
                     done = !(F < INFINITY);
                     if (!done && (nact * 2u <= nact_ref)) { // half of them have finished: re-fit the frustum
-#if !defined(GRT_TILE_REFIT_FULL) && defined(GRT_TILE_PLANES_LDS) // (round 4: C2 -2 %, C3 / C5 -0.2 %; -DGRT_TILE_REFIT_FULL: all twelve reductions again)
                         GRT_FRUSTUM_(act, !BUNDLE)
-#else
-                        GRT_FRUSTUM(act)
-#endif
                         LIM = uni(wave_fmax(act ? ct_ : 0.0f));
                         lim_dirty = false;
                         nact_ref = nact;
@@ -963,8 +732,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 // any later pass (a lane came back: its cut-off did fall short).  Behind a moving front the arrivals are
                 // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
-                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + GRT_PRUNE_ROOM >= a.ovf_entries);
-                    if (GRT_RARE(wave_any(pr_))) { // wave-uniform, rare
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + kPruneRoom >= a.ovf_entries);
+                    if (wave_any(pr_)) { // wave-uniform, rare
                         bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
                         lim_dirty = true;
                     }
@@ -974,7 +743,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     while (true) {
                         const bool cl_ = alive && (k0 != kKeyInvalid) && (key_t(k0) < F) && (k0 < lost);
                         if (!wave_any(cl_)) break;
-                        GRT_D5(hit_evals)
+                        GRT_D(hit_evals, 1)
                         const uint64_t ek = wave_umin64(cl_ ? k0 : kKeyInvalid);
                         const bool own = cl_ && (k0 == ek); // exactly one lane: a particle is tested once per pass
                         const uint64_t om = wave_ballot(own);
@@ -1032,16 +801,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                                              wave_any(can_ && ((KPRESS != kKeyInvalid) || (T < kSweepEagerT)));
                             if (!go_) break;
                         }
-                        if (GRT_RARE(!cm_)) {
+                        if (!cm_) {
                             // ---- refill: one scan of the bags of the lanes in need; entry by entry, whatever is smaller
                             //      than the window's last key goes in (sorted insert) and the displaced last key takes
                             //      its place in the bag (compacted in place: position w <= i) ----
-#ifndef GRT_TILE_DIAG4
                             GRT_D(node_visits, 1)
-#endif
                             // lanes that do not need it yet but have room for four more keys come along: one scan instead
                             // of one per lane a few steps apart
-                            const bool rf = need || (alive && (nb != 0u) && (GRT_RF_ROOM == kKeyInvalid) && (bagmin < lost));
+                            const bool rf = need || (alive && (nb != 0u) && (KROOM == kKeyInvalid) && (bagmin < lost));
                             uint32_t nmax = rf ? nb : 0u;
                             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
                             nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
@@ -1090,15 +857,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
                         }
                         if (!cm_) continue;
-                        GRT_D5(hit_evals)
-#if GRT_TILE_COST_WORK
-                        if (MODE == 0) work += GRT_COST_WC;
-#endif
-#ifdef GRT_TILE_ACC_LDS
-                        const float4 ac_ = acc_lds[lane];
-                        float T = ac_.w;
-                        f3 radiance = mk3(ac_.x, ac_.y, ac_.z);
-#endif
+                        GRT_D(hit_evals, 1)
                         const uint64_t ek = k0;
                         const uint32_t cell = (uint32_t)(ek & kCellMask);
                         const uint32_t id = skey_id(ek);
@@ -1150,9 +909,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         // (same value, (L T) alpha per channel with the T of before the event; placed here so that the gather of
                         //  color0 has the window pop and the re-key to hide behind)
                         if (!SH && blend_) radiance = add3(radiance, mul3s(mul3s(mk3(cc.x, cc.y, cc.z), T_old), ea));
-#ifdef GRT_TILE_ACC_LDS
-                        acc_lds[lane] = make_float4(radiance.x, radiance.y, radiance.z, T);
-#endif
                     }
                 }
                 if (done) break;
@@ -1181,11 +937,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const bool occ_l = fr != kNoRoot;
                 const bool rng_l = occ_l && ((fr & kLeafBit) != 0u);
                 bool leaf_step;
-                float hz_sel = -INFINITY; // (GRT_TILE_CHAIN) the look-ahead horizon of this step's selection; depth-first mode: none
-                (void)hz_sel;
-                bool dense_ = false;      // GRT_TILE_DEFER: this leaf step had more candidate ranges than it can take (nearest ones chosen)
-                float step_th = INFINITY; // ... and the box bound of the farthest range it took
-                (void)dense_; (void)step_th;
                 uint32_t nref; // the entry this lane's group expands
                 uint32_t ngrp; // groups in this step (wave-uniform): group g is valid when g < ngrp
                 uint32_t g, j; // group of this lane and its child slot in the group: 4 lanes per leaf range, kTileWide per node
@@ -1207,11 +958,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     const bool crowded = (nocc > 64u - a.tile_reserve) && have_rng;
                     // nodes within the look-ahead of the FRONT are expanded first, so that leaf steps find full batches;
                     // then the nearest ranges (within a band behind the nearest one) are tested together
-#ifndef GRT_TILE_LOOK_MUL
-#define GRT_TILE_LOOK_MUL 1.0f
-#endif
-                    const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs * GRT_TILE_LOOK_MUL) : F * look_);
-                    hz_sel = hz;
+                    const float hz = F + (PIECES ? fmaxf(F * look_, a.tile_band_abs) : F * look_);
                     const bool node_near = (occm_ & ~rngm_ & wave_ballot(fl <= hz)) != 0ull;
                     leaf_step = have_rng && (!node_near || crowded);
                     // the nearest range / node: the frontier minimum when it is of that kind (the common case), else one
@@ -1237,7 +984,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         float lo_ = wave_min(cand ? fl : INFINITY), hi_ = tau; // the nearest candidate itself always qualifies
                         // (MODE 2 looks far ahead: bisect between the nearest and the farthest candidate, twice as finely)
                         if (SINGLE) hi_ = fminf(tau, uni(wave_fmax((cand && (fl <= tau)) ? fl : 0.0f)));
-                        for (int it = 0; it < GRT_BISECT; it++) {
+                        for (int it = 0; it < kBisect; it++) {
                             const float mid = 0.5f * (lo_ + hi_);
                             const uint32_t n_ = (uint32_t)__popcll(candm_ & wave_ballot(fl <= mid));
                             const bool few = n_ <= maxb;
@@ -1247,19 +994,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         }
                         th = lo_;
                         sm = candm_ & wave_ballot(fl <= th);
-                        dense_ = leaf_step;
                     }
-                    step_th = th;
                     const bool selm = cand && (fl <= th);
                     const uint32_t rk = lanes_below(sm);
                     const bool sel = selm && (rk < maxb);
                     const uint32_t cnt = min((uint32_t)__popcll(sm), maxb);
-#ifdef GRT_TILE_DIAG4 /* with -DGRT_TILE_DIAG: rounds = occupied frontier slots summed over the steps, node_visits / stall_exits = entries a node / leaf step took, hit_evals += bag entries */
-                    if (COUNT) { w.rounds += nocc; if (leaf_step) w.stall_exits += cnt; else w.node_visits += cnt; w.segments += 0u; }
-#endif
-#ifdef GRT_TILE_DIAG5 /* with -DGRT_TILE_DIAG -DGRT_TILE_DIAG4: steps by the number of lanes that still want something: rays <= 2, segments <= 4, hit_evals <= 8, proxy_tests <= 16, fetches = all steps */
-                    if (COUNT) { w.rays += nact_cur <= 2u; w.segments += nact_cur <= 4u; w.hit_evals += nact_cur <= 8u; w.proxy_tests += nact_cur <= 16u; w.fetches += 1u; }
-#endif
                     if (sel) xsel[rk] = fr;
                     fl = sel ? INFINITY : fl;
                     fr = sel ? kNoRoot : fr;
@@ -1267,21 +1006,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     nref = xsel[g];
                     ngrp = cnt;
                 }
-#ifdef GRT_TILE_CHAIN
-#define GRT_STEP_DONE break     /* out of the chain loop, whose end is the end of the step loop's body */
-#else
-#define GRT_STEP_DONE continue
-#endif
-#ifdef GRT_TILE_CHAIN
-                // EXPERIMENT (round 4, profiles/r04_experiments_log.md 18): a node step whose surviving children include a FEW internal nodes
-                // within the look-ahead expands those at once — the box tests and the compaction again, without the loop top (frontier
-                // minimum, wanting lanes, compositing check) and the selection in between: on a deep tree of large overlapping boxes a
-                // tile's steps take one or two nodes each, one wide level per step.
-                uint32_t chain_depth = 0;
-                bool bail = false;
-                for (;;) {
-                uint32_t chained = 0;
-#endif
                 const uint32_t first = leaf_first(nref);
                 // (one compare per condition, made where it is voted on: a condition that arrives from another block as a
                 //  bool is voted on through a 0 / 1 register and a second compare)
@@ -1297,7 +1021,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const uint32_t cref = leaf_step ? (first + j) : __float_as_uint(b0.w); // particle index / child ref
                 const bool valid = cv && (cref != kNoRoot);
                 if (COUNT && valid) c.node_visits++; // one 32-B child box per lane
-                if (GRT_RARE(lim_dirty)) { // a window overflowed: lanes past their cutoff want nothing any more
+                if (lim_dirty) { // a window overflowed: lanes past their cutoff want nothing any more
                     const float ct2_ = (lost != kKeyInvalid) ? key_t(lost) : t_hi_m;
                     LIM = uni(wave_fmax(alive ? ct2_ : 0.0f));
                     lim_dirty = false;
@@ -1315,13 +1039,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 const float cx_ = lx_ + hx_, cy_ = ly_ + hy_, cz_ = lz_ + hz_;
                 const float gx_ = hx_ - lx_, gy_ = hy_ - ly_, gz_ = hz_ - lz_;
                 const float rs_ = b1.w + b1.w;
-#ifdef GRT_TILE_PLANES_LDS
                 // (shadows of the pass-level values: read back from LDS; the near side is the box's hi side where the slab factor is negative)
                 const float4 fq0 = ((const float4*)fr_lds)[0], fq1 = ((const float4*)fr_lds)[1], fq2 = ((const float4*)fr_lds)[2], fq3 = ((const float4*)fr_lds)[3];
                 const float pLx = fq0.x, pLy = fq0.y, pLz = fq0.z, pRx = fq0.w, pRy = fq1.x, pRz = fq1.y, pBx = fq1.z, pBy = fq1.w;
                 const float pBz = fq2.x, pTx = fq2.y, pTy = fq2.z, pTz = fq2.w, ivx = fq3.x, ivy = fq3.y, ivz = fq3.z;
                 const bool shx = ivx < 0.0f, shy = ivy < 0.0f, shz = ivz < 0.0f;
-#endif
 #define GRT_PSIDE(P, MP)                                                                                   \
                 ((__builtin_fmaf(P##x, cx_, __builtin_fmaf(P##y, cy_, P##z * cz_)) +                        \
                   fminf(__builtin_fmaf(fabsf(P##x), gx_, __builtin_fmaf(fabsf(P##y), gy_, fabsf(P##z) * gz_)), rs_)) >= \
@@ -1349,7 +1071,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 lam = fmaxf(lam, F); // never below the current front (keeps the frontier monotone)
                 bool want = valid & inside & (lam <= LIM);
                 uint64_t wm = wave_ballot(g < ngrp) & wave_ballot(j < jmax_) & wave_ballot(cref != kNoRoot) & insidem_ & wave_ballot(lam <= LIM);
-                if (GRT_RARE(LO > 0.0f)) { // later passes: skip what ends before the restart point
+                if (LO > 0.0f) { // later passes: skip what ends before the restart point
                     const float fx_ = fmaxf(fabsf(lx_), fabsf(hx_)), fy_ = fmaxf(fabsf(ly_), fabsf(hy_)),
                                 fz_ = fmaxf(fabsf(lz_), fabsf(hz_));
                     float far = sqrtf(__builtin_fmaf(fx_, fx_, __builtin_fmaf(fy_, fy_, fz_ * fz_))) * (1.0f + 2e-6f);
@@ -1359,194 +1081,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                 }
 
                 if (leaf_step) {
-                    GRT_D5(fetches)
-#if GRT_TILE_COST_WORK
-                    if (MODE == 0) work += GRT_COST_WF * (uint32_t)__popcll(wm);
-#endif
+                    GRT_D(fetches, 1)
+                    if (MODE == 0) work += kCostFetch * (uint32_t)__popcll(wm);
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
-#ifdef GRT_TILE_DIAG2
-                    uint32_t d2_sum = 0, d2_prev = 0, d2_passes = 0;
-#endif
-#ifdef GRT_TILE_DEFER
-                    // EXPERIMENT (profiles/r04_experiments_log.md, item 9): an order among overlapping proxies.  In a dense region the step
-                    // takes the nearest ranges BY BOX, and a box's bound is early by up to a proxy's diameter: hundreds of proxies are
-                    // slab-tested before the rays — which saturate a few dozen events in — ever reach them.  So when the step had to choose
-                    // (more candidates than it can take), every survivor is first given a TIGHT lower bound of its entry: the smallest
-                    // entry into its circumscribed sphere in Gaussian space over the lanes the pre-test lets through (the quantities the
-                    // pre-test forms anyway).  A range whose surviving particles all start beyond the box bound of the farthest range
-                    // taken goes back on the frontier with that bound — other ranges are nearer than it — and one that no lane can touch
-                    // is dropped; the rest is tested as ever.  A range is deferred at most once (its bound is tight from then on).
-                    if (!SINGLE && dense_ && wm != 0ull) {
-                        float lamp = INFINITY;
-                        uint64_t w1 = wm;
-                        const uint64_t alive1_ = wave_ballot(alive);
-                        while (w1 != 0ull) {
-                            const uint32_t b = (uint32_t)__builtin_ctzll(w1);
-                            w1 = clear_bit64(w1, b);
-                            const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b) << 6;
-                            float4 r0, r1, r2, r3, e0, e1, e2, e3;
-                            sload64(a.rec, roff, r0, r1, r2, r3);
-                            if (!BUNDLE) sload64(a.erec, roff, e0, e1, e2, e3);
-                            if (COUNT) c.fetches += BUNDLE ? 4 : 8;
-                            m33 A;
-                            A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
-                            A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
-                            A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-                            const f3 o_g = BUNDLE ? matvec(A, sub3(o, mk3(r0.x, r0.y, r0.z))) : mk3(e0.x, e0.y, e0.z);
-                            const float cc_ = BUNDLE ? proxy_sphere_cc(o_g, r0.w) : e0.w;
-                            const f3 d_g = matvec(A, d);
-                            const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
-                            const bool inside_ = cc_ <= 0.0f;
-                            const bool pass_ = alive && (inside_ || (b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_));
-                            // first root of aa t^2 + 2 b t + cc = 0; outside and moving away (b >= 0): the sphere lies behind the ray
-                            const float disc_ = fmaxf(b_ * b_ - aa_ * cc_, 0.0f);
-                            const float tsp_ = (-b_ - __builtin_amdgcn_sqrtf(disc_)) * __builtin_amdgcn_rcpf(fmaxf(aa_, 1e-30f));
-                            const float tl_ = inside_ ? 0.0f : ((b_ < 0.0f) ? fmaxf(tsp_ * (1.0f - 4e-5f) - 1e-30f, 0.0f) : INFINITY);
-                            const float lp_ = uni(wave_fmin((pass_ && (alive1_ != 0ull)) ? tl_ : INFINITY));
-                            lamp = (lane == b) ? lp_ : lamp;
-                        }
-                        // the smallest bound among a range's particles (4 lanes per range; non-negative floats order as integers)
-                        uint32_t lq = __float_as_uint(want ? lamp : INFINITY);
-                        lq = min(lq, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lq, 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
-                        lq = min(lq, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lq, 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
-                        const float lamr = __uint_as_float(lq);
-                        const bool none_ = !(lamr < INFINITY);               // no lane can touch any particle of the range
-                        const bool later_ = !none_ && (lamr > step_th);       // its particles start beyond what this step reaches
-                        const bool back_ = later_ && gv && (j == 0u) && (fmaxf(lamr, F) <= LIM);
-                        const uint64_t backm = wave_ballot(back_);
-                        if (backm) { // back onto the frontier (the step freed at least as many slots as it took ranges)
-                            const uint32_t crk = lanes_below(backm);
-                            if (back_) xch[crk] = make_uint2(__float_as_uint(fmaxf(lamr, F)), nref);
-                            wave_fence();
-                            const uint64_t fm = wave_ballot(fr == kNoRoot);
-                            const uint32_t frk = lanes_below(fm);
-                            if ((fr == kNoRoot) && (frk < (uint32_t)__popcll(backm))) {
-                                const uint2 v = xch[frk];
-                                fl = __uint_as_float(v.x);
-                                fr = v.y;
-                            }
-                            wave_fence();
-                        }
-                        wm &= ~(wave_ballot(none_) | wave_ballot(later_));
-                        want = want && !none_ && !later_;
-                        GRT_D(stall_exits, 0)
-                    }
-#endif
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
                     const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
-                    if (PAIRS) {
-                        uint32_t nsl = 0, npr = 0; // survivors staged, pairs listed (wave-uniform)
-                        while (true) {
-                            const bool have = wm != 0ull;
-                            if (!have && nsl == 0u) break;
-                            uint64_t m_ = 0ull;
-                            uint32_t cnt_ = 0;
-                            float vrec = 0.0f;
-                            if (have) {
-                                const uint32_t b = (uint32_t)__builtin_ctzll(wm);
-                                wm = clear_bit64(wm, b);
-                                const uint32_t pidx = (uint32_t)__builtin_amdgcn_readlane((int)cref, (int)b);
-                                const uint32_t roff = pidx << 6;
-                                // the two records once more by a VECTOR load, for their LDS copy (the scalar cache does not feed LDS):
-                                // lanes 0-15 the record's dwords, 16-31 the eye record's
-                                if (lane < 32u) vrec = *(const float*)((const char*)((lane < 16u) ? (const void*)a.rec : (const void*)a.erec) + roff + (lane & 15u) * 4u);
-                                float4 r0, r1, r2, r3, e0, e1, e2, e3;
-                                sload64(a.rec, roff, r0, r1, r2, r3);
-                                sload64(a.erec, roff, e0, e1, e2, e3);
-                                (void)e1; (void)e2; (void)e3; (void)r0;
-                                if (COUNT) c.fetches += 8;
-                                m33 A;
-                                A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
-                                A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
-                                A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-                                const f3 o_g = mk3(e0.x, e0.y, e0.z);
-                                const f3 d_g = matvec(A, d);
-                                const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
-                                m_ = (wave_ballot(e0.w <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * e0.w)) & alivem_;
-                                if (!m_) continue;
-                                cnt_ = (uint32_t)__popcll(m_);
-                                if (COUNT && alive) c.proxy_tests++;
-                            }
-                            if (nsl != 0u && (!have || npr + cnt_ > 64u || nsl == 4u)) {
-                                // ---- one pass over the listed pairs: lanes = (ray, particle) pairs ----
-                                {
-                                    const bool pv = lane < npr;
-                                    const uint32_t pe = pv ? pr_list[lane] : 0u;
-                                    const int pray = (int)(pe & 63u);
-                                    const f3 dd = mk3(__shfl(d.x, pray), __shfl(d.y, pray), __shfl(d.z, pray));
-                                    const float4* sp = (const float4*)(pr_stg + (pe >> 6) * 32u);
-                                    // (three rounds of LDS reads, fenced so that the compiler does not hoist all 32 dwords at once:
-                                    //  the kernel sits at its register limit)
-                                    f3 dg2;
-                                    {
-                                        const float4 q1 = sp[1], q2 = sp[2], q3 = sp[3];
-                                        m33 A2;
-                                        A2.a[0] = q1.x; A2.a[1] = q1.y; A2.a[2] = q1.z;
-                                        A2.a[3] = q2.x; A2.a[4] = q2.y; A2.a[5] = q2.z;
-                                        A2.a[6] = q3.x; A2.a[7] = q3.y; A2.a[8] = q3.z;
-                                        dg2 = matvec(A2, dd);
-                                    }
-                                    wave_fence();
-                                    float te2, tx2;
-                                    bool h2;
-                                    {
-                                        const float4 f1 = sp[5], f2 = sp[6], f3q = sp[7];
-                                        const float s2 = pr_stg[(pe >> 6) * 32u + 3u];
-                                        float pa2[10];
-                                        pa2[0] = f1.x; pa2[1] = f1.y; pa2[2] = f1.z; pa2[3] = f1.w; pa2[4] = f2.x; pa2[5] = f2.y; pa2[6] = f2.z;
-                                        pa2[7] = f2.w; pa2[8] = f3q.x; pa2[9] = f3q.y;
-                                        h2 = proxy_slabs_pre(pa2, dg2, s2, te2, tx2) && pv;
-                                    }
-                                    wave_fence();
-                                    float al2;
-                                    {
-                                        const float4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3], f0 = sp[4];
-                                        m33 A2;
-                                        A2.a[0] = q1.x; A2.a[1] = q1.y; A2.a[2] = q1.z;
-                                        A2.a[3] = q2.x; A2.a[4] = q2.y; A2.a[5] = q2.z;
-                                        A2.a[6] = q3.x; A2.a[7] = q3.y; A2.a[8] = q3.z;
-                                        al2 = fminf(0.99f, response_from(A2, mk3(q0.x, q0.y, q0.z), o, dd, mk3(f0.x, f0.y, f0.z), dg2) * q1.w);
-                                    }
-                                    if (pv) { pr_res[lane] = h2 ? te2 : INFINITY; pr_res[64u + lane] = tx2; pr_res[128u + lane] = al2; }
-                                    wave_fence();
-                                }
-                                // ---- the results back to the rays: one insert round per staged survivor, lanes = rays ----
-                                uint32_t pb = 0;
-                                for (uint32_t sl = 0; sl < nsl; sl++) {
-                                    const uint2 mk = pr_mask[sl];
-                                    const uint64_t m2 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.x) |
-                                                        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.y) << 32);
-                                    const uint32_t pid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pr_stg[sl * 32u + 11u]));
-                                    const bool mine = ((m2 >> lane) & 1ull) != 0ull;
-                                    const uint32_t q_ = pb + lanes_below(m2);
-                                    float te = INFINITY, tx = 0.0f, al = 0.0f;
-                                    if (mine) { te = pr_res[q_]; tx = pr_res[64u + q_]; al = pr_res[128u + q_]; }
-                                    const bool hit = mine && (te <= tx) && alive;
-                                    pb += (uint32_t)__popcll(m2);
-                                    GRT_TILE_INSERT(te, tx, hit, pid, al, 0.0f, mk3(0, 0, 0), mk3(0, 0, 0), 0u)
-                                }
-                                wave_fence();
-                                nsl = 0u;
-                                npr = 0u;
-                            }
-                            if (!have) break;
-                            // ---- stage the survivor: its records, its pairs, its mask ----
-                            if (lane < 32u) pr_stg[nsl * 32u + lane] = vrec;
-                            if ((m_ >> lane) & 1ull) pr_list[npr + lanes_below(m_)] = lane | (nsl << 6);
-                            if (lane == 0u) pr_mask[nsl] = make_uint2((uint32_t)m_, (uint32_t)(m_ >> 32));
-                            wave_fence();
-                            npr += cnt_;
-                            nsl++;
-                        }
-                        GRT_STEP_DONE; // (the step is over: on to the next trip of the step loop)
-                    }
                     while (SINGLE ? trip : (wm != 0ull)) {
                         trip = false;
                         float4 r0, r1, r2, r3, e0, e1, e2, e3;
                         bool act_; // lanes the exact test is meant for
-#ifdef GRT_TILE_PROBE
-                        uint32_t ridx_probe_ = 0u;
-#endif
                         if (SINGLE) { // every surviving lane fetches and tests ITS particle
                             act_ = want && alive;
                             r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1563,15 +1106,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             // (a 32-bit BYTE offset: the two 64-B scalar loads take it as their SGPR offset, no 64-bit address
                             //  arithmetic; the launcher sends scenes of 2^26 primitives and more elsewhere, kTileMaxPrims)
                             const uint32_t roff = pidx << 6;
-#ifdef GRT_TILE_PROBE
-                            ridx_probe_ = pidx * 4u;
-#endif
                             sload64(a.rec, roff, r0, r1, r2, r3);
                             if (!BUNDLE) sload64(a.erec, roff, e0, e1, e2, e3);
                             if (COUNT) c.fetches += BUNDLE ? 4 : 8; // wave-uniform: 64-B record (+ 64-B eye record), in 16-B units
                             act_ = alive;
                         }
-                        GRT_D5(segments)
+                        GRT_D(segments, 1)
                         if (MODE == 1) work++;
                         const f3 mu = mk3(r0.x, r0.y, r0.z);
                         m33 A;
@@ -1587,39 +1127,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             const uint64_t m_ = (wave_ballot(cc_ <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_)) &
                                                 (SINGLE ? wave_ballot(act_) : alivem_);
                             if (!m_) continue;
-#ifdef GRT_TILE_DIAG2
-                            if (COUNT) {
-                                const uint32_t pc_ = (uint32_t)__popcll(m_);
-                                w.rays += pc_;
-                                d2_sum += pc_;
-                                if (d2_prev && d2_prev + pc_ <= 64u) d2_prev = 0u; else { d2_passes++; d2_prev = pc_; }
-                            }
-#endif
                         }
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
-#if GRT_TILE_COST_WORK
-                        if (MODE == 0) work += GRT_COST_WT;
-#endif
-                        GRT_D5(proxy_tests)
-#ifdef GRT_TILE_PROBE // sensitivity probes (profiles/r03_sensitivity.json): extra work per exact test, results untouched
-                        {
-                            float pr0_ = d_g.x, pr1_ = d_g.y;
-                            uint32_t ps_ = ridx_probe_;
-#pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_VDEP; q_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pr0_));
-#pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_VIND; q_++)
-                                asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pr0_), "+v"(pr1_));
-#pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_SALU; q_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ps_) : : "scc");
-#pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_NOP; q_++) asm volatile("s_nop 1");
-#pragma unroll
-                            for (int q_ = 0; q_ < GRT_PROBE_TRIP; q_++)
-                                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "+s"(ps_) : "s"(a.rec + (ps_ & 0xffffu)) : "memory");
-                        }
-#endif
+                        if (MODE == 0) work += kCostTest;
+                        GRT_D(proxy_tests, 1)
                         float te, tx;
                         float pa[10]; // slab_project(o_g)
                         if (BUNDLE) {
@@ -1628,37 +1140,76 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                             pa[0] = e1.x; pa[1] = e1.y; pa[2] = e1.z; pa[3] = e1.w; pa[4] = e2.x; pa[5] = e2.y; pa[6] = e2.z;
                             pa[7] = e2.w; pa[8] = e3.x; pa[9] = e3.y;
                         }
-#ifdef GRT_TILE_EARLY_OUT
-                        const bool hit = proxy_slabs_pre<SINGLE ? 0 : GRT_TILE_EARLY_OUT>(pa, d_g, r0.w, te, tx, act_) && act_;
-#else
                         const bool hit = proxy_slabs_pre(pa, d_g, r0.w, te, tx) && act_;
-#endif
-#ifdef GRT_TILE_DIAG2
-                        if (COUNT) { const uint64_t hm_ = wave_ballot(hit); w.hit_evals += (uint32_t)__popcll(hm_); w.node_visits += hm_ ? 1u : 0u; }
-#endif
-                        GRT_TILE_INSERT(te, tx, hit, __float_as_uint(r2.w), fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w), r0.w, o_g, d_g, __float_as_uint(r3.w))
+                        // ---- the particle's events into the lanes' windows: keys of the entry / exit events inside the lane's interval,
+                        //      piece ownership, the response (computed only when some lane inserts), window overflow into the lane's bag,
+                        //      sorted insert.  (> last_key, not just > pass_lo, with pieces: a particle that entered the tree as several pieces
+                        //      is met once per piece the tile crosses, with the same keys; float compares first: te / tx may be negative or
+                        //      NaN, the unsigned key compares assume t > 0; alpha does not depend on the hit distance, shaders/tracer.cuh:
+                        //      354-357; window full: the largest pending key leaves — into the lane's bag in global memory, or for good: the
+                        //      lane is then lossy beyond it.)
+                        const uint32_t id = __float_as_uint(r2.w);
+                        const uint64_t ke = mk_skey(te, id, 0), kx = mk_skey(tx, id, 1);
+                        const uint64_t seen_ = PIECES ? last_key : pass_lo;
+                        bool in_e = hit && (te >= t_lo) && (te < t_hi) && (ke > seen_);
+                        bool in_x = hit && (tx >= t_lo) && (tx < t_hi) && (kx > seen_);
+                        const uint32_t cellb = PIECES ? __float_as_uint(r3.w) : 0u;
+                        if (PIECES && cellb) {
+                            const bool own_ = piece_owns(cellb, r0.w, o_g, d_g, in_e ? te : tx);
+                            in_e = in_e && own_;
+                            in_x = in_x && own_;
+                        }
+                        const uint64_t k_first = in_e ? ke : (in_x ? kx : kKeyInvalid);
+                        const bool ins = (k_first != kKeyInvalid) && (k_first < lost);
+                        GRT_TILE_CHECK_FRONT(ins, k_first)
+                        if (wave_any(ins)) {
+                            const float alpha = fminf(0.99f, response_from(A, mu, o, d, o_g, d_g) * r1.w);
+                            const float other = (in_e && in_x) ? tx : INFINITY;
+                            const bool full = KLAST != kKeyInvalid;
+                            const bool take = ins && (!full || k_first < KLAST);
+                            const bool drop = ins && full;
+                            const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
+                            if (wave_any(drop)) {
+                                if (!SINGLE && chunk == kNoRoot) {
+                                    uint32_t ch = 0;
+                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u);
+                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u);
+                                }
+                                const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost);
+                                if (to_bag) {
+                                    const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
+                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
+                                        make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a);
+                                    nb++;
+                                    bagmin = (dk < bagmin) ? dk : bagmin;
+                                }
+                                const bool gone = drop && !to_bag;
+                                lost = (gone && (dk < lost)) ? dk : lost;
+                                if (SINGLE) lost = wave_umin64(lost);
+                                else bags = true;
+                                if (wave_any(gone)) lim_dirty = true;
+                            }
+                            KLAST = (take && full) ? kKeyInvalid : KLAST;
+                            pmask = take ? (pmask | (1u << cell)) : pmask;
+                            if (take) { PL_OTHER(cell) = other; PL_ALPHA(cell) = alpha; }
+                            if (SINGLE && take) {
+                                f3 L;
+                                if (!SH) {
+                                    const float4 cc = a.color0[id];
+                                    L = mk3(cc.x, cc.y, cc.z);
+                                } else {
+                                    L = sh_radiance(a.sh + (size_t)id * 48, dn, a.p.sh_degree_max);
+                                }
+                                PL_COL(cell, 0) = L.x; PL_COL(cell, 1) = L.y; PL_COL(cell, 2) = L.z;
+                            }
+                            SLOT_INSERT(take ? (k_first | (uint64_t)cell) : kKeyInvalid)
+                        }
                     }
-#if defined(GRT_TILE_DIAG2) && !defined(GRT_TILE_DIAG3)
-                    if (COUNT) { w.rounds += (d2_sum + 63u) / 64u; w.stall_exits += d2_passes; }
-#endif
-                    GRT_STEP_DONE; // (the step is over: on to the next trip of the step loop)
+                    continue; // (the step is over: on to the next trip of the step loop)
                 }
-                GRT_D5(rays)
-#ifdef GRT_TILE_CHAIN
-                if (MODE == 0 && wm && chain_depth < GRT_TILE_CHAIN) {
-                    const bool nxt = want && ((cref & kLeafBit) == 0u) && (lam <= hz_sel);
-                    const uint64_t nm_ = wave_ballot(nxt);
-                    const uint32_t nn_ = (uint32_t)__popcll(nm_);
-                    const uint32_t nf0_ = (uint32_t)__popcll(wave_ballot(fr == kNoRoot)), nc0_ = (uint32_t)__popcll(wm);
-                    // (their children will need slots and they free none: only while the frontier has room for all of them)
-                    if (nn_ != 0u && nn_ <= 64u / kTileWide && nf0_ >= (nc0_ - nn_) + nn_ * kTileWide + a.tile_reserve) {
-                        if (nxt) xsel[lanes_below(nm_)] = cref;
-                        want = want && !nxt;
-                        wm &= ~nm_;
-                        chained = nn_;
-                    }
-                }
-#endif
+                GRT_D(rays, 1)
                 // ---- node step: compaction of the wanted children into free frontier slots; what does not fit goes
                 //      to the depth-first stack ----
                 if (wm) {
@@ -1677,9 +1228,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                     } else {
                         if (nc > nf && dsp + (nc - nf) > kStack) { // cannot happen for the tree heights the launcher admits
                             c.stall_exits += alive ? 1u : 0u;
-#ifdef GRT_TILE_CHAIN
-                            bail = true;
-#endif
                             if (MODE == 1) { aborted = true; break; }
                             watchdog = true;
                             iters |= kCostStackBit;
@@ -1700,30 +1248,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
                         wave_fence();
                     }
                 }
-#ifdef GRT_TILE_CHAIN
-                if (!chained) break;
-                wave_fence();
-                g = lane / kTileWide;
-                j = lane % kTileWide;
-                nref = xsel[g];
-                ngrp = chained;
-                leaf_step = false;
-                chain_depth++;
-                iters++; // (a chained level is a step of the tile: the cost word, the watchdog)
-                } // chain loop
-                if (bail) break;
-#endif
             }
-#ifdef GRT_TILE_REBAL_OUT
-            if (!need_rebal) break;
-            need_rebal = false;
-            {
-                float Ff_;
-                do_rebalance((uint32_t)__popcll(wave_ballot(fr != kNoRoot)), Ff_);
-                skip_rebal = true; // (at least one step between two rebalances, as with the in-place call)
-            }
-            } // for (;;)
-#endif
             // a lane goes again only if it dropped something and still has transmittance left
             if (aborted) break;
             const bool progressed = last_key != pass_lo;
@@ -1738,24 +1263,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             alive = ((again && (stalls < 2u)) || parked) && !watchdog;
         }
         // (unit and part code are taken from the ONE scalar that lives across the passes, the order entry)
-#if GRT_TILE_COST_WORK
-        // the cost word: steps + the weighted particle work (GRT_COST_W*, above).  The watchdog's reading of it, "steps > max_iters"
+        // the cost word: steps + the weighted particle work (kCostFetch, kCostTest).  The watchdog's reading of it, "steps > max_iters"
         // (k_check_costs), stays exact: the word is kept at or below max_iters unless the watchdog fired.
         if (!BUNDLE && a.cost && lane == 0) {
-#if GRT_TILE_COST_WORK == 2 /* EXPERIMENT: the wave's own elapsed time (s_memtime, in units of GRT_COST_TSHIFT cycles) */
-            uint32_t cw = min(((uint32_t)__builtin_amdgcn_s_memtime() - t0_lds) >> GRT_COST_TSHIFT, kCostStepsMask);
-#else
             uint32_t cw = min((iters & kCostStepsMask) + (work >> 3), kCostStepsMask);
-#endif
             cw = watchdog ? max(cw, min(a.max_iters, kCostStepsMask - 1u) + 1u) : min(cw, a.max_iters);
             atomicMax(&a.cost[ue & kOrderUnitMask], (iters & ~kCostStepsMask) | cw | ((ue >> 30) << kCostPartShift));
         }
-#else
-        if (!BUNDLE && a.cost && lane == 0) atomicMax(&a.cost[ue & kOrderUnitMask], iters | ((ue >> 30) << kCostPartShift));
-#endif
-#ifdef GRT_TILE_ACC_LDS
-        if (!SINGLE) { const float4 ac_ = acc_lds[lane]; T = ac_.w; radiance = mk3(ac_.x, ac_.y, ac_.z); }
-#endif
     }
     if (MODE == 1 && aborted) { // wave-uniform: nothing is written, the chunk's rays join the heavy list
         const uint64_t vm = wave_ballot(in_frame);
@@ -1851,9 +1365,6 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
             a.out8[out_idx * 3 + 2] = quantize8(col.z);
         }
     }
-#ifdef GRT_TILE_DIAG2
-    w.segments = w2.segments; w.proxy_tests = w2.proxy_tests; w.fetches = w2.fetches;
-#endif
 #ifdef GRT_TILE_DIAG
     if (COUNT) { c = (lane == 0) ? w : Cnt(); c.fetches = w.fetches; }
 #endif
@@ -1882,12 +1393,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 1 ? GRT
 }
 
 #undef GRT_IN_PART
-#undef GRT_STEP_DONE
-#undef GRT_TILE_INSERT
 #undef GRT_TILE_CHECK_FRONT
 #undef KS
 #undef KLAST
 #undef KPRESS
+#undef KROOM
 #undef PL_OTHER
 #undef PL_ALPHA
 #undef PL_COL

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""isa_budget_current.py [--marks file.s] — the register / LDS / spill budget of every kernel the library ships, from the device
-assembly the build keeps (gaussian-ray-tracing_amd/csrc/build_asm/*.s, written by hipcc_via_asm.py) -> profiles/isa_budget_current.json.
+"""isa_budget_current.py [--marks file.s] [--out file.json] — the register / LDS / spill budget of every kernel the library ships, from the
+device assembly the build keeps (gaussian-ray-tracing_amd/csrc/build_asm/*.s, written by hipcc_via_asm.py) -> build_asm/isa_budget.json
+(an untracked build artefact: tests/test_isa_lint.py reads it, and regenerates it when the assembly is newer; `--out profiles/isa_budget_rNN.json`
+writes the reviewed snapshot a round commits).
 
 Why: the tile kernel's frame time follows its resident waves (128 VGPRs and <= 9984 B of LDS = 16 waves per CU; 13 waves:
 +22 %) and the register allocation of its hot loop re-draws with every edit (an atomicOr cost 13-16 %, a 30-line cold block
@@ -19,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ASM = os.path.join(ROOT, "gaussian-ray-tracing_amd", "csrc", "build_asm")
-OUT = os.path.join(ROOT, "profiles", "isa_budget_current.json")
+OUT = os.path.join(ASM, "isa_budget.json")
 C3_KERNEL = "_ZN3grt12_GLOBAL__N_113k_render_tileILb0ELb0ELb0ELi0ELb0EEEvNS_10RenderArgsE"
 
 
@@ -113,8 +115,17 @@ def sections(lines):
     return [{"section": n, **instr_stats(c)} for n, c in pieces]
 
 
-def main():
-    marks = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--marks" else None
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    marks, out = None, OUT
+    while argv:
+        if argv[0] == "--marks":
+            marks = argv[1]
+        elif argv[0] == "--out":
+            out = argv[1]
+        else:
+            raise SystemExit(__doc__)
+        argv = argv[2:]
     res = {"source": "gaussian-ray-tracing_amd/csrc/build_asm/*.s (the assembly the shipped objects were assembled from)", "kernels": []}
     for path in sorted(glob.glob(os.path.join(ASM, "*.s"))):
         if path.endswith("_marks.s"):
@@ -138,8 +149,8 @@ def main():
                                                  "build": "-DGRT_MARKS (the markers are empty asm statements: the allocation may differ slightly from the shipped object's)",
                                                  "vgprs": ks[C3_KERNEL][0].get("vgpr_count"), "scratch_bytes": ks[C3_KERNEL][0].get("private_segment_fixed_size"),
                                                  "sections": sections(ks[C3_KERNEL][1])}
-    json.dump(res, open(OUT, "w"), indent=1)
-    print(f"isa budget: {len(res['kernels'])} kernels -> {os.path.relpath(OUT, ROOT)}")
+    json.dump(res, open(out, "w"), indent=1)
+    print(f"isa budget: {len(res['kernels'])} kernels -> {os.path.relpath(out, ROOT)}")
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@
    (gaussian-ray-tracing_amd/csrc/hipcc_via_asm.py; the cause of round 3's "not understood" watchdog failure).  The
    build repairs it; here the assembly the shipped objects were assembled from must be clean, and the repair itself is
    checked on the recorded failing snippet.
-3. ISA budget: profiles/isa_budget_current.json (written by build()) — the camera-ray kernel's frame time follows its
+3. ISA budget: csrc/build_asm/isa_budget.json (written by build(); regenerated here when the kept assembly is newer) — the camera-ray kernel's frame time follows its
    resident waves (<= 128 VGPRs, <= 9984 B of LDS per wave: 16 waves per CU; 13 waves cost 22 %) and its spill count
    re-draws with every edit: the limits are asserted so that such a change fails here, not at the bench."""
 import glob
@@ -168,8 +168,13 @@ def test_shipped_assembly_has_no_spill_code_in_front_of_an_exec_restore():
 
 
 def _budget():
-    p = os.path.join(ROOT, "profiles", "isa_budget_current.json")
-    assert os.path.exists(p), "profiles/isa_budget_current.json is written by __graft_entry__.build()"
+    """the budget of the assembly that is there NOW: the JSON is a build artefact beside it, made again when any kept .s is newer"""
+    files = _built_asm()
+    p = os.path.join(CSRC, "build_asm", "isa_budget.json")
+    if not os.path.exists(p) or os.path.getmtime(p) < max(os.path.getmtime(f) for f in files):
+        import subprocess
+        marks = os.path.join(CSRC, "build_asm", "grt_render_tile_marks.s")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "profiles", "isa_budget_current.py")] + (["--marks", marks] if os.path.exists(marks) else []))
     return {k["kernel"]: k for k in json.load(open(p))["kernels"]}
 
 
