@@ -425,13 +425,17 @@ static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
 // above the step watchdog = the watchdog fired, high bits = stack guard / two passes without progress.  One pass over
 // the costs right behind the frame ORs them into the context's sticky error word.
 // behind every frame (do_launch): error word and overflow demand to their pinned host words, overflow counter reset
+// (d_ovf_next[0] = chunks this frame asked for, [1] = the largest demand since the host last took one: the pinned word is written
+//  only when the host is not waiting for an earlier value — h_ovf_used == nullptr otherwise — so a peak between two reads is kept)
 __global__ void k_frame_tail(const uint32_t* __restrict__ d_err, uint32_t* __restrict__ h_err, uint32_t* __restrict__ d_ovf_next,
                              uint32_t* __restrict__ h_ovf_used)
 {
     *h_err = *d_err;
     if (d_ovf_next) {
-        *h_ovf_used = *d_ovf_next;
-        *d_ovf_next = 0u;
+        const uint32_t peak = max(d_ovf_next[1], d_ovf_next[0]);
+        d_ovf_next[0] = 0u;
+        d_ovf_next[1] = h_ovf_used ? 0u : peak;
+        if (h_ovf_used) *h_ovf_used = peak;
     }
     __threadfence_system();
 }
@@ -624,7 +628,10 @@ int grt_set_option(grt_ctx* c, int option, int value)
         if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
         c->opt_ovf_entries = value;
     }
-    else if (option == GRT_OPT_MAX_ITERS) { c->opt_max_iters = std::max(0, value); }
+    else if (option == GRT_OPT_MAX_ITERS) { // (the steps travel in 27 bits of the tile's cost word: a limit the word cannot exceed could never be reported)
+        if (value < 0 || (uint32_t)value > kCostStepsMask - 1u) { c->err = "GRT_OPT_MAX_ITERS: 0 (default) .. 2^27 - 2"; return GRT_ERR_INVALID; }
+        c->opt_max_iters = value;
+    }
     else if (option == GRT_OPT_COST_RADIUS) { c->opt_cost_radius = std::min(8, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_PARTS2_PCT) { c->opt_tile_parts2_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PARTS4_PCT) { c->opt_tile_parts4_pct = std::min(100, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
@@ -1101,6 +1108,10 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_order, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u))); // (+ 3 diagnostic words)
+        // (every entry starts as padding: an entry the ordering kernels ever failed to write would make its wave exit instead of
+        //  indexing costs, queues and pixels with whatever the allocation held — the likely cause of round 4's one unexplained abort,
+        //  profiles/r05_experiments_log.md 1)
+        CHK(c, hipMemset(c->d_order, 0xFF, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u)));
         if (!c->d_ord_scratch) { // counts and cursors of the several-workgroup ordering (grt_bvh.hip: k_ord_a); zero once, phase C keeps it so
             CHK(c, hipMalloc(&c->d_ord_scratch, order_scratch_bytes()));
             CHK(c, hipMemset(c->d_ord_scratch, 0, order_scratch_bytes()));
@@ -1321,7 +1332,11 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     if (tile_kernel) {
         int rco = size_overflow_pool(c, a.n_blocks * 4u);
         if (rco != GRT_OK) return rco;
-        if (!c->d_ovf_next) CHK(c, hipMalloc(&c->d_ovf_next, sizeof(uint32_t)));
+        if (!c->d_ovf_next) { // [0] next free chunk, [1] running peak of the demand (k_frame_tail)
+            CHK(c, hipMalloc(&c->d_ovf_next, 2 * sizeof(uint32_t)));
+            CHK(c, hipMemset(c->d_ovf_next, 0, 2 * sizeof(uint32_t)));
+            c->ovf_zeroed = true;
+        }
     }
     CHK(c, hipEventRecord(c->ev0, s));
     a.erec = nullptr;
@@ -1426,7 +1441,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     // host word (sizes the pool of the frames to come), and their counter reset for the next frame
     {
         uint32_t* ovf = (rc == GRT_OK) ? a.ovf_next : nullptr;
-        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->h_ovf_used);
+        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->ovf_pending ? (uint32_t*)nullptr : c->h_ovf_used);
         if (hipGetLastError() == hipSuccess) {
             tail = true;
             if (ovf) {

@@ -1267,8 +1267,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
         // (k_check_costs), stays exact: the word is kept at or below max_iters unless the watchdog fired.
         if (!BUNDLE && a.cost && lane == 0) {
             uint32_t cw = min((iters & kCostStepsMask) + (work >> 3), kCostStepsMask);
-            cw = watchdog ? max(cw, min(a.max_iters, kCostStepsMask - 1u) + 1u) : min(cw, a.max_iters);
-            atomicMax(&a.cost[ue & kOrderUnitMask], (iters & ~kCostStepsMask) | cw | ((ue >> 30) << kCostPartShift));
+            // (max_iters <= kCostStepsMask - 1: grt_set_option; a stack-guard give-up has its own bit and is not a step watchdog)
+            const bool over = watchdog && !(iters & kCostStackBit);
+            cw = over ? max(cw, a.max_iters + 1u) : min(cw, a.max_iters);
+            atomicMax(&a.cost[ue & kOrderUnitMask], (iters & (kCostStackBit | kCostStallBit)) | cw | ((ue >> 30) << kCostPartShift));
         }
     }
     if (MODE == 1 && aborted) { // wave-uniform: nothing is written, the chunk's rays join the heavy list

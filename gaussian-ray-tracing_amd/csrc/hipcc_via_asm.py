@@ -13,11 +13,10 @@ expired", "absurd counters"); the SHIPPED round-3 library had the same pattern i
 
 Steps (what `hipcc -c` does, with one stop in the middle):
   1. hipcc --cuda-device-only -S           -> device assembly
-  2. exec-prologue repair                   where everything EXEC-dependent between the start of a machine basic block and
-                                            the `s_or_b64 exec, exec, s[..]` in it is of the register allocator's own
-                                            making (spill store / reload, rematerialised constant), those instructions
-                                            move BEHIND the restore (they were meant for the join block: all lanes);
-                                            then the same rule, as a lint, must find nothing
+  2. exec-prologue lint + repair            a labelled block whose first EXEC write widens EXEC must have nothing EXEC-dependent
+                                            in front of that write (structural: see "the rule" below); VGPR spill stores found
+                                            there move BEHIND the restore when nothing depends on their place, anything else
+                                            fails the build with the snippet; then the lint must find nothing
                                             (profiles/tools/exec_prologue_lint.py applies it to any assembly file)
   3. clang -x assembler, lld, clang-offload-bundler -> fat binary
   4. hipcc --cuda-host-only -fcuda-include-gpubinary -> the object
@@ -34,52 +33,159 @@ LLVM = os.path.join(ROCM, "lib", "llvm", "bin")
 HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 ARCH = os.environ.get("GRT_ARCH", "gfx950")
 
-EXEC_FREE = re.compile(r"^(s_|v_readlane_b32|v_writelane_b32|v_readfirstlane_b32|;|\.)")
+# ---- the rule ------------------------------------------------------------------------------------------------------------
+# (A) structural.  A block that is the target of an `s_cbranch_execz` is a JOIN block: on that edge it is entered with
+#     EXEC = 0, so the compiler never schedules EXEC-dependent work between its label and the instruction that widens EXEC
+#     again (s_or_b64 exec, exec, s[..] / s_mov_b64 exec, s[..] / s_or_saveexec_b64) — what stands there was put there by the
+#     register allocator at the "top of the block" (spill stores / reloads, rematerialised constants) and runs under the
+#     partial mask of the branch that just ended.  ANY EXEC-dependent instruction there (vector ALU, vector / scratch / LDS
+#     memory, v_readfirstlane) is an offender, whatever it looks like.
+# (B) by the allocator's marks.  Elsewhere (a join block whose skip branch was removed is reached by falling through only,
+#     `; %bb.N:`; an out-of-line then-block carries a label too) ordinary vector work in front of a restore is a then-branch
+#     that block placement merged with its join: it belongs under the partial mask.  There a block is taken for a join only
+#     when EVERYTHING EXEC-dependent between its top and the restore is of the allocator's own making (`Folded Spill` /
+#     `Folded Reload`, constant moves) and at least one spill / reload is among it.
+# Either scan ends at the block's top, at a branch, at any earlier EXEC write of the block and at a hand-written asm region
+# (those save and restore EXEC themselves: tests/test_isa_lint.py); restores INSIDE asm regions are not looked at.
+#
+# The repair is deliberately narrow: offenders move behind the restore only when ALL of them are VGPR spill STORES
+# (`scratch_store_dword* ... ; N-byte Folded Spill`: the value of the lanes that skipped the branch must reach the slot too)
+# and nothing that stays between a moved store and the restore waits on the vector-memory counter or names a moved register
+# (s_waitcnt vmcnt / v_readlane / v_writelane: their order against the store would change).  Anything else — a reload, a
+# rematerialised constant (a then-branch's phi copy looks the same), a dependence — FAILS the build with the snippet.
+EXEC_WRITE = re.compile(r"^(s_\w+\s+exec\b|s_\w+_saveexec_b64\b|v_cmpx_)")
+WIDEN = re.compile(r"^(s_or_b64 exec, exec, s\[\d+:\d+\]|s_mov_b64 exec, s\[\d+:\d+\]|s_or_saveexec_b64 s\[\d+:\d+\], s\[\d+:\d+\])")
+EXEC_FREE = re.compile(r"^(s_|v_readlane_b32|v_writelane_b32|;|\.)")
 BLOCK_END = re.compile(r"^s_(cbranch|branch|endpgm|setpc)")
-RESTORE = re.compile(r"^s_or_b64 exec, exec, s\[\d+:\d+\]")
-LABEL = re.compile(r"^[.\w$]+:")
-# what the register allocator inserts on its own: spill stores / reloads (the assembly printer marks them) and
-# rematerialised constants
+LABEL = re.compile(r"^([.\w$]+):")
+SPILL_STORE = re.compile(r"^scratch_store_dword(x[234])?\b.*;\s*\d+-byte Folded Spill")
 RA_MADE = re.compile(r"^(scratch_(store|load)_dword(x[234])?\b.*;\s*\d+-byte Folded (Spill|Reload)|"
                      r"v_mov_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|v_mov_b64_e32 v\[\d+:\d+\], (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|"
                      r"v_bfrev_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9]+)\s*$)")
+# offenders of rule (A) accepted as they stand, by opcode, each with its reason (none today)
+WHITELIST = {}
 
 
-def block_prologue_offenders(L, i):
-    """Line i is an EXEC restore.  When everything EXEC-dependent between the start of its machine basic block and i is of
-    the register allocator's own making (spill store / reload, rematerialised constant), the block is a join block and
-    those instructions were meant for ALL its lanes: their indices.  (A block whose front holds ordinary vector work is a
-    then-branch that block placement merged with its join block: that work belongs under the partial mask.)"""
-    out = []
-    k = i - 1
-    while k >= 0:
-        u = L[k].strip()
-        if LABEL.match(u) or u.startswith("; %bb.") or BLOCK_END.match(u):
-            break
-        if u.startswith(";;#ASMEND"):
-            break  # hand-written asm manages EXEC itself
-        if u and not EXEC_FREE.match(u):
-            if not RA_MADE.match(u):
+def vgprs_of(t):
+    """VGPR numbers an instruction names (v7, v[4:7])"""
+    out = set()
+    for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", t.split(";")[0]):
+        if m.group(1):
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+class Asm:
+    """the lines of a device assembly file, which of them lie inside hand-written asm regions, and the join labels"""
+
+    def __init__(self, text):
+        self.L = text.split("\n")
+        self.in_asm = []
+        inside = False
+        self.execz_targets = set()
+        for l in self.L:
+            u = l.strip()
+            if u.startswith(";;#ASMSTART"):
+                inside = True
+            self.in_asm.append(inside)
+            if u.startswith(";;#ASMEND"):
+                inside = False
+            m = re.match(r"^s_cbranch_execz\s+([.\w$]+)", u)
+            if m:
+                self.execz_targets.add(m.group(1))
+
+    def offenders(self, i):
+        """Line i widens EXEC (outside asm regions): the indices of the instructions in front of it that run under the
+        wrong mask by rule (A) or (B), else []."""
+        L = self.L
+        dep = []
+        k = i - 1
+        top = None
+        # (`s_mov_b64 exec, s[a:b]` with s[a:b] formed by a scalar instruction of this very block — the expanded form of
+        #  s_and_saveexec_b64 when the saved mask is spilled — narrows EXEC: the start of an if, not a join)
+        msrc = re.match(r"^s_mov_b64 exec, (s\[\d+:\d+\])", L[i].strip())
+        while k >= 0:
+            u = L[k].strip()
+            if msrc and re.match(r"^s_\w+\s+" + re.escape(msrc.group(1)) + r"\s*,", u):
                 return []
-            out.append(k)
-        k -= 1
-    return sorted(out) if any("Folded" in L[k] for k in out) else []
+            m = LABEL.match(u)
+            if m and not self.in_asm[k]:
+                top = m.group(1)
+                break
+            if u.startswith("; %bb."):
+                top = ""
+                break
+            if BLOCK_END.match(u) or u.startswith(";;#ASMEND") or EXEC_WRITE.match(u):
+                return []  # behind a branch / behind hand-written asm / not the block's first EXEC write
+            if u and not EXEC_FREE.match(u):
+                dep.append(k)
+            k -= 1
+        if top is None or not dep:
+            return []
+        if top in self.execz_targets:  # rule (A)
+            return sorted(k for k in dep if L[k].strip().split()[0] not in WHITELIST)
+        if all(RA_MADE.match(L[k].strip()) for k in dep) and any("Folded" in L[k] for k in dep):  # rule (B)
+            return sorted(dep)
+        return []
+
+    def block_top(self, i):
+        k = i - 1
+        while k >= 0 and not ((LABEL.match(self.L[k].strip()) and not self.in_asm[k]) or self.L[k].strip().startswith("; %bb.")):
+            k -= 1
+        return k
+
+    def why_not_movable(self, i, off):
+        """None when the offenders in front of the restore at line i may simply move behind it, else the reason why not."""
+        L = self.L
+        moved = set()
+        for k in off:
+            u = L[k].strip()
+            if not SPILL_STORE.match(u):
+                return f"not a VGPR spill store: {u}"
+            moved |= vgprs_of(u)
+        for k in range(off[0] + 1, i):  # what stays between the first moved store and the restore
+            if k in off:
+                continue
+            u = L[k].strip()
+            if not u or u.startswith(";") or u.startswith("."):
+                continue
+            if re.match(r"^s_waitcnt\b.*vmcnt", u):
+                return f"an s_waitcnt on the vector-memory counter stays between a moved store and the restore: {u}"
+            if vgprs_of(u) & moved:
+                return f"an instruction that stays between a moved store and the restore names a moved register: {u}"
+        return None
+
+    def snippet(self, i):
+        return "\n".join("    " + self.L[k] for k in range(max(self.block_top(i), i - 24), i + 1))
+
+
+class ExecPrologueError(Exception):
+    pass
 
 
 def repair(text):
-    L = text.split("\n")
+    A = Asm(text)
+    L = A.L
     moved = []
     i = 0
     while i < len(L):
-        if RESTORE.match(L[i].strip()):
-            off = block_prologue_offenders(L, i)
+        if WIDEN.match(L[i].strip()) and not A.in_asm[i]:
+            off = A.offenders(i)
             if off:
+                why = A.why_not_movable(i, off)
+                if why:
+                    raise ExecPrologueError(f"EXEC-dependent instructions in front of a join block's EXEC restore (line {i + 1}) that the "
+                                            f"build will not move on its own — {why}\n{A.snippet(i)}")
                 ins = [L[k] for k in off]
                 for k in reversed(off):
                     del L[k]
+                    del A.in_asm[k]
                 i -= len(off)
                 for n, l in enumerate(ins):
                     L.insert(i + 1 + n, l + "  ; moved behind the EXEC restore (hipcc_via_asm.py)")
+                    A.in_asm.insert(i + 1 + n, False)
                 moved += [l.strip() for l in ins]
                 i += len(ins)
         i += 1
@@ -87,11 +193,11 @@ def repair(text):
 
 
 def lint(text):
-    L = text.split("\n")
+    A = Asm(text)
     bad = []
-    for i, l in enumerate(L):
-        if RESTORE.match(l.strip()):
-            bad += [(k + 1, L[k].strip()) for k in block_prologue_offenders(L, i)]
+    for i, l in enumerate(A.L):
+        if WIDEN.match(l.strip()) and not A.in_asm[i]:
+            bad += [(k + 1, A.L[k].strip()) for k in A.offenders(i)]
     return bad
 
 
@@ -126,7 +232,11 @@ def main():
         text = open(s0).read()
         moved = []
         if not norepair:
-            text, moved = repair(text)
+            try:
+                text, moved = repair(text)
+            except ExecPrologueError as e:
+                sys.stderr.write(f"hipcc_via_asm: {src}: {e}\n")
+                sys.exit(1)
             left = lint(text)
             if left:
                 sys.stderr.write(f"hipcc_via_asm: {src}: EXEC-dependent instructions still in front of an EXEC restore:\n")

@@ -202,16 +202,26 @@ float GaussianTracer::lastKernelMs()
     return ms;
 }
 
-// ---- HIPOutputBuffer (src/CUDAOutputBuffer.cpp:3-64) ----
+// ---- HIPOutputBuffer (src/CUDAOutputBuffer.cpp:3-64); the GL-interop form is HIPOutputBufferGL.cpp ----
+#ifdef GRT_WITH_GL
+HIPOutputBuffer::HIPOutputBuffer(int32_t width, int32_t height, bool gl_interop) : m_gl(gl_interop) { resize(width, height); }
+#else
 HIPOutputBuffer::HIPOutputBuffer(int32_t width, int32_t height) { resize(width, height); }
+void HIPOutputBuffer::resizeGL(int32_t, int32_t) {}
+void HIPOutputBuffer::releaseGL() {}
+uchar3* HIPOutputBuffer::mapGL() { return nullptr; }
+void HIPOutputBuffer::unmapGL() {}
+#endif
 HIPOutputBuffer::~HIPOutputBuffer()
 {
+    if (m_gl) releaseGL();
     hipglue::deviceFree(m_device);
     hipglue::hostFreePinned(m_host);
 }
 void HIPOutputBuffer::resize(int32_t width, int32_t height)
 {
-    if (m_width == width && m_height == height && m_device) return;
+    if (m_width == width && m_height == height && (m_device || m_pbo)) return;
+    if (m_gl) { resizeGL(width, height); return; }
     hipglue::deviceFree(m_device);
     hipglue::hostFreePinned(m_host);
     m_device = nullptr; m_host = nullptr;
@@ -220,10 +230,17 @@ void HIPOutputBuffer::resize(int32_t width, int32_t height)
     m_device = static_cast<uchar3*>(hipglue::deviceAlloc(bytes));
     m_host = static_cast<uchar3*>(hipglue::hostAllocPinned(bytes));
 }
-void HIPOutputBuffer::unmap() { hipglue::copyToHostAsync(m_host, m_device, (size_t)m_width * m_height * 3, m_stream); }
+uchar3* HIPOutputBuffer::map() { return m_gl ? mapGL() : m_device; }
+void HIPOutputBuffer::unmap()
+{
+    if (m_gl) unmapGL();
+    else hipglue::copyToHostAsync(m_host, m_device, (size_t)m_width * m_height * 3, m_stream);
+}
 const std::vector<unsigned char>& HIPOutputBuffer::download()
 {
     m_copy.resize((size_t)m_width * m_height * 3);
-    hipglue::copyToHost(m_copy.data(), m_device, m_copy.size());
+    const uchar3* src = m_gl ? mapGL() : m_device; // (GL: the PBO is mapped for the copy and handed back)
+    hipglue::copyToHost(m_copy.data(), src, m_copy.size());
+    if (m_gl) unmapGL();
     return m_copy;
 }

@@ -24,7 +24,7 @@ def main():
     for p in sys.argv[1:]:
         text = open(p).read()
         f = V.lint(text)
-        n = sum(1 for l in text.split("\n") if V.RESTORE.match(l.strip()))
+        n = sum(1 for l in text.split("\n") if V.WIDEN.match(l.strip()))
         print(f"{p}: {n} EXEC restores, {len(f)} register-allocator-made instruction(s) in front of one inside its join block")
         L = text.split("\n")
         for ln, t in f:

@@ -142,16 +142,70 @@ FAILING = """\
 """
 
 
-def test_exec_prologue_repair_on_the_recorded_failure():
+def test_exec_prologue_lint_and_narrow_repair_on_the_recorded_failure():
+    # the lint names both instructions; the build does NOT move a rematerialised constant on its own (a then-branch's phi copy
+    # looks the same: ADVICE r04) — it fails with the snippet
     assert [t for _, t in V.lint(FAILING)] == ["v_mov_b32_e32 v17, 0x7f800000", "scratch_store_dword off, v115, off      ; 4-byte Folded Spill"]
-    fixed, moved = V.repair(FAILING)
-    assert len(moved) == 2 and V.lint(fixed) == []
+    with pytest.raises(V.ExecPrologueError, match="not a VGPR spill store: v_mov_b32_e32 v17"):
+        V.repair(FAILING)
+    # the spill store alone is what the repair is for: it moves behind the restore, the waitcnt IN FRONT of it stays where it is
+    store_only = FAILING.replace("\tv_mov_b32_e32 v17, 0x7f800000\n", "")
+    fixed, moved = V.repair(store_only)
+    assert len(moved) == 1 and V.lint(fixed) == []
     L = [l.split(";")[0].strip() for l in fixed.split("\n")]
     r = L.index("s_or_b64 exec, exec, s[12:13]")
-    assert L[r - 1] == "s_waitcnt vmcnt(1)" and L[r + 1].startswith("v_mov_b32_e32 v17") and L[r + 2].startswith("scratch_store_dword off, v115")
+    assert L[r - 1] == "s_waitcnt vmcnt(1)" and L[r + 1].startswith("scratch_store_dword off, v115")
     # a then-branch that block placement merged with its join block is ordinary work under the partial mask: left alone
     merged = "; %bb.264:\n\tv_lshlrev_b32_e32 v3, 2, v3\n\tds_write_b32 v3, v35 offset:9856\n\ts_or_b64 exec, exec, s[6:7]\n"
     assert V.lint(merged) == [] and V.repair(merged)[1] == []
+
+
+def test_exec_prologue_repair_refuses_what_depends_on_its_place():
+    # a RELOAD in front of the restore, its s_waitcnt and the v_readlane that consumes it: not moved, the build fails
+    reload = """\
+\ts_cbranch_execz .LBB3_9
+; %bb.8:
+\tv_add_f32_e32 v2, v2, v3
+.LBB3_9:
+\tscratch_load_dword v44, off, off offset:12 ; 4-byte Folded Reload
+\ts_waitcnt vmcnt(0)
+\tv_readlane_b32 s6, v44, 3
+\tv_readlane_b32 s7, v44, 4
+\ts_or_b64 exec, exec, s[6:7]
+"""
+    assert len(V.lint(reload)) == 1
+    with pytest.raises(V.ExecPrologueError, match="not a VGPR spill store"):
+        V.repair(reload)
+    # a spill store whose register a lane move BEHIND it (staying in front of the restore) writes, or with a vmcnt wait behind it
+    for tail, why in (("\tv_writelane_b32 v115, s4, 2\n", "names a moved register"), ("\ts_waitcnt vmcnt(0)\n", "vector-memory counter")):
+        t = ".LBB1_2:\n\tscratch_store_dword off, v115, off      ; 4-byte Folded Spill\n" + tail + "\ts_or_b64 exec, exec, s[12:13]\n"
+        assert len(V.lint(t)) == 1
+        with pytest.raises(V.ExecPrologueError, match=why):
+            V.repair(t)
+
+
+def test_exec_prologue_lint_is_structural_at_join_labels():
+    # rule (A): the target of an s_cbranch_execz is entered with EXEC = 0 — ANYTHING EXEC-dependent between its label and the
+    # restore is wrong there, marked by the allocator or not (a constant move, an LDS write, a v_readfirstlane)
+    for ins in ("v_mov_b32_e32 v3, 0", "ds_write_b32 v3, v35 offset:16", "v_readfirstlane_b32 s4, v9", "global_load_dword v4, v[4:5], off"):
+        t = f"\ts_and_saveexec_b64 s[6:7], vcc\n\ts_cbranch_execz .LBB2_4\n; %bb.3:\n\tv_add_f32_e32 v1, v1, v2\n.LBB2_4:\n\t{ins}\n\ts_or_b64 exec, exec, s[6:7]\n"
+        assert [x for _, x in V.lint(t)] == [ins], ins
+        with pytest.raises(V.ExecPrologueError):
+            V.repair(t)
+    # ... while an OUT-OF-LINE then-block (a label reached by s_cbranch_execnz) holds ordinary work in front of its copy of the restore
+    outl = "\ts_and_saveexec_b64 s[18:19], vcc\n\ts_cbranch_execnz .LBB13_28\n.LBB13_20:\n\ts_or_b64 exec, exec, s[18:19]\n\ts_endpgm\n" \
+           ".LBB13_28:\n\tv_lshl_add_u64 v[4:5], v[2:3], 2, s[16:17]\n\tglobal_load_dword v4, v[4:5], off\n\ts_or_b64 exec, exec, s[18:19]\n"
+    assert V.lint(outl) == []
+    # the scan ends at an earlier EXEC write of the block (what stands behind it runs under the mask that write made) ...
+    behind = ".LBB4_7:\n\ts_andn2_b64 exec, exec, s[0:1]\n\tscratch_store_dword off, v9, off ; 4-byte Folded Spill\n\ts_or_b64 exec, exec, s[2:3]\n"
+    assert V.lint(behind) == []
+    # ... restores inside hand-written asm regions are the region's own business, and labels in there do not open blocks ...
+    region = ".LBB5_1:\n\t;;#ASMSTART\n\ts_mov_b64 s[18:19], exec\n\t.Lgrt_e2_0:\n\tv_cmp_lt_u64 s[24:25], v[80:81], v[44:45]\n\ts_mov_b64 exec, s[24:25]\n" \
+             "\tv_mov_b64 v[44:45], v[80:81]\n\ts_mov_b64 exec, s[18:19]\n\t;;#ASMEND\n"
+    assert V.lint(region) == []
+    # ... and `s_mov_b64 exec, sN` with sN formed in the block itself is the expanded s_and_saveexec_b64 of an if: it narrows EXEC
+    narrow = "\ts_cbranch_execz .LBB6_280\n.LBB6_280:\n\tv_mov_b32_e32 v82, 0\n\ts_mov_b64 s[0:1], exec\n\ts_and_b64 s[0:1], s[0:1], s[4:5]\n\ts_mov_b64 exec, s[0:1]\n"
+    assert V.lint(narrow) == []
 
 
 def _built_asm():
@@ -198,3 +252,26 @@ def test_isa_budget_of_the_render_kernels():
     assert c3["lane_moves"] <= 165 and c3["lane_moves_in_loops"] <= 145 and c3["spilled_sgprs"] <= 8 and c3["instructions"] <= 5200, c3
     c5 = b["grt::k_render_tile<false, false, false, 0, true>"]  # the same with pieces (needle / sheet scenes)
     assert c5["spill_instructions_in_loops"] <= 2 and c5["spill_instructions"] <= 16, c5  # (two in its piece-ownership block)
+
+
+def test_non_default_configurations_of_the_tile_kernel_compile_and_pass_the_lints(tmp_path):
+    """The compile-time variants the tile kernel still has (GRT_TILE_DIAG: trip counters; GRT_TILE_CHECK: invariant checks;
+    GRT_MARKS: section marks; GRT_TILE_KS = 8 is the single-ray translation unit of every build) go through the same
+    hipcc -> assembly -> lint -> assembler path as the shipped objects, so that none of them rots unseen."""
+    import subprocess
+    flags = subprocess.check_output(["make", "-s", "-C", CSRC, "print-flags"], text=True).split()
+    hipcc = subprocess.check_output(["make", "-s", "-C", CSRC, "print-hipcc"], text=True).strip()
+    env = dict(os.environ, HIPCC=hipcc)
+    procs = []
+    for name, extra in (("diag", ["-DGRT_TILE_DIAG"]), ("check", ["-DGRT_TILE_CHECK"]), ("marks", ["-DGRT_MARKS"])):
+        out = tmp_path / name
+        out.mkdir()
+        cmd = [sys.executable, os.path.join(CSRC, "hipcc_via_asm.py"), "--keep-asm", str(out), str(out / "tile.o"),
+               os.path.join(CSRC, "grt_render_tile.hip")] + flags + extra
+        procs.append((name, out, subprocess.Popen(cmd, cwd=CSRC, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for name, out, p in procs:
+        log = p.communicate()[0]
+        assert p.returncode == 0, f"-D variant '{name}' does not build:\n{log[-3000:]}"
+        text = open(out / "tile.s").read()
+        assert V.lint(text) == [], name
+        assert (out / "tile.o").stat().st_size > 100000
