@@ -428,9 +428,10 @@ static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
 // (d_ovf_next[0] = chunks this frame asked for, [1] = the largest demand since the host last took one: the pinned word is written
 //  only when the host is not waiting for an earlier value — h_ovf_used == nullptr otherwise — so a peak between two reads is kept)
 __global__ void k_frame_tail(const uint32_t* __restrict__ d_err, uint32_t* __restrict__ h_err, uint32_t* __restrict__ d_ovf_next,
-                             uint32_t* __restrict__ h_ovf_used)
+                             uint32_t* __restrict__ h_ovf_used, const uint32_t* __restrict__ d_qpcount, uint32_t* __restrict__ h_qpcount)
 {
     *h_err = *d_err;
+    if (d_qpcount) *h_qpcount = d_qpcount[0]; // how many four-way parts the quad kernel's list holds (a launch that knows it is none skips that kernel)
     if (d_ovf_next) {
         const uint32_t peak = max(d_ovf_next[1], d_ovf_next[0]);
         d_ovf_next[0] = 0u;
@@ -486,7 +487,7 @@ int grt_create(grt_ctx** out, int device)
         (e = hipMalloc(&c->d_n_heavy, sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc(&c->d_err, sizeof(uint32_t))) != hipSuccess || (e = hipMemset(c->d_err, 0, sizeof(uint32_t))) != hipSuccess ||
         (e = hipHostMalloc(&c->h_ovf_used, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc(&c->h_err, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_err, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess || // [0] error word, [1] parts in the quad list
         (e = hipEventCreateWithFlags(&c->ev_ovf, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming)) != hipSuccess) {
         g_create_err = std::string("grt_create: ") + hipGetErrorString(e);
@@ -544,7 +545,7 @@ static void free_slot_state(grt_ctx* c)
 {
     (void)hipFree(c->d_erec); (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
-    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch);
+    (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch); (void)hipFree(c->d_qparts); (void)hipFree(c->d_qpcount);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
@@ -638,6 +639,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_STATIC_SHARP) { c->opt_static_sharp = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_ORDER_MULTI_MIN) { c->opt_order_multi_min = std::max(1, value); }
     else if (option == GRT_OPT_MESH_PARTS) { c->opt_mesh_parts = value != 0; c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_QUAD_PARTS) { c->opt_quad_parts = std::max(0, value); c->cost_valid = false; c->order_ready = false; } // (2: whatever the launch's size; > 2: and that many parts at most — testing)
     else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
     else if (option == GRT_OPT_TILE_RESERVE) { c->opt_tile_reserve = std::min(63, std::max(-1, value)); }
@@ -1055,6 +1057,25 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // the default XCD-chunked order.
 // launch order of the units from the costs the last frame left in d_cost (dilated for full-frame launches)
 static uint32_t parts_extra_cap(uint32_t n_units) { return n_units / 4u + 64u; } // launch entries beyond one per tile
+// four-way parts on the quad kernel: camera rays without meshes or pieces (that kernel has no mesh stage and no piece bookkeeping; such
+// frames keep part waves of the camera-ray kernel)
+// — and launches that the parts of their heaviest tiles BOUND: between half and three times the machine's resident waves (measured,
+// profiles/r05_experiments_log.md 4: a rank's share of a 1080p frame, 4050 / 8100 tiles, 0.77 -> 0.55 / 0.75 -> 0.61 ms; a 256^2 frame
+// of 1024 tiles is bound by how its thousand waves spread over the machine and a 720p frame of 14 400 by its total work: both lose
+// 5 % to the second kernel).  GRT_OPT_QUAD_PARTS = 2 forces it on whatever the size (tests).
+static bool quad_parts_ok(const grt_ctx* c, uint32_t n_units)
+{
+    const grt_ctx* sc = scene_of(c);
+    if (!c->opt_quad_parts || sc->n_faces || sc->has_pieces) return false;
+    return c->opt_quad_parts >= 2 || (n_units >= kTileResidentWaves / 2u && n_units <= 3u * kTileResidentWaves);
+}
+// the four-way threshold such launches use: parts on the quad kernel cost a third of what part waves of the camera-ray kernel cost, so
+// more tiles are worth splitting the fewer tiles there are per resident wave — pct4 at two tiles per wave, half of it at one and below
+static uint32_t quad_pct4(const grt_ctx* c, uint32_t n_units)
+{
+    const uint32_t p = (uint32_t)c->opt_tile_parts4_pct;
+    return std::min(p, std::max(p / 2u, (uint32_t)((uint64_t)p * n_units / (2u * kTileResidentWaves))));
+}
 
 static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, hipStream_t s, bool* used_split, bool zero_costs = false)
 {
@@ -1078,10 +1099,19 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         // tile kernel, camera rays, no meshes: the heaviest tiles of this frame run as 2 / 4 waves in the next one
         *used_split = false;
         const uint32_t cap = parts_extra_cap(n_units);
+        const bool quad = quad_parts_ok(c, n_units) && c->d_qparts;
         int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
-                                         (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, c->d_ord_scratch,
+                                         quad ? quad_pct4(c, n_units) : (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, c->d_ord_scratch,
                                          (uint32_t)c->opt_order_multi_min, s, &c->err);
-        if (rcp == GRT_OK) c->order_launch = n_units + cap;
+        if (rcp == GRT_OK) {
+            c->order_launch = n_units + cap;
+            c->qparts_valid = false;
+            if (quad) { // the four-way parts as a list for the quad kernel (one more small kernel behind the ordering)
+                rcp = quad_part_list(c->d_order, c->order_launch, c->d_qparts, c->d_qpcount, (uint32_t)c->opt_quad_parts > 2u ? (uint32_t)c->opt_quad_parts : kQuadListCap, s, &c->err);
+                c->qparts_valid = rcp == GRT_OK;
+                c->qlist_epoch++;
+            }
+        }
         return rcp;
     }
     *used_split = split;
@@ -1102,8 +1132,9 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
                              ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
                              ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
     if (c->cost_cap < n_units) {
-        (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil);
-        c->d_cost = c->d_order = c->d_cost_dil = nullptr;
+        (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_qparts);
+        c->d_cost = c->d_order = c->d_cost_dil = c->d_qparts = nullptr;
+        c->qparts_valid = false;
         c->cost_cap = 0;
         c->cost_valid = false;
         CHK(c, hipMalloc(&c->d_cost, sizeof(uint32_t) * n_units));
@@ -1117,6 +1148,11 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             CHK(c, hipMemset(c->d_ord_scratch, 0, order_scratch_bytes()));
         }
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
+        CHK(c, hipMalloc(&c->d_qparts, sizeof(uint32_t) * kQuadListCap));
+        if (!c->d_qpcount) {
+            CHK(c, hipMalloc(&c->d_qpcount, 2 * sizeof(uint32_t)));
+            CHK(c, hipMemset(c->d_qpcount, 0, 2 * sizeof(uint32_t)));
+        }
         c->cost_cap = n_units;
     }
     if (!c->opt_feedback) { // no scheduling feedback: the cost words are only collected for k_check_costs (tile kernel)
@@ -1181,7 +1217,15 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             rc = order_units_with_parts(src, c->d_cost_dil, c->d_order, n_units, cap, 0u, (uint32_t)c->opt_cold_parts_pct,
                                         (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, nullptr, c->d_ord_scratch,
                                         (uint32_t)c->opt_order_multi_min, s, &c->err);
-            if (rc == GRT_OK) { c->order_launch = n_units + cap; a.n_launch = c->order_launch; }
+            if (rc == GRT_OK) {
+                c->order_launch = n_units + cap; a.n_launch = c->order_launch;
+                c->qparts_valid = false;
+                if (quad_parts_ok(c, n_units) && c->d_qparts) {
+                    rc = quad_part_list(c->d_order, c->order_launch, c->d_qparts, c->d_qpcount, (uint32_t)c->opt_quad_parts > 2u ? (uint32_t)c->opt_quad_parts : kQuadListCap, s, &c->err);
+                    c->qparts_valid = rc == GRT_OK;
+                    c->qlist_epoch++;
+                }
+            }
         } else {
             rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, nullptr, s, &c->err);
         }
@@ -1260,6 +1304,10 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     // the zeroing / ordering queued behind the last frame ran on THAT frame's stream: a launch on another stream waits
     // for it (else it could start before its counters are reset — two tiles taking the same overflow chunk)
     if (c->tail_pending && c->tail_stream != s) CHK(c, hipStreamWaitEvent(s, c->ev_tail, 0));
+    // (has the work behind the last frame finished?  then the pinned words it wrote are current: the error word, and how many parts
+    //  the quad kernel's list holds)
+    const bool tail_done = !c->tail_pending || hipEventQuery(c->ev_tail) == hipSuccess;
+    if (tail_done && c->tail_qepoch != ~0ull) { c->qknown_epoch = c->tail_qepoch; c->qknown_count = c->h_err[1]; } // (the list that tail saw, and its length)
     c->tail_pending = false;
     {
         // the streaming kernel runs one 8x8 tile (one wave) per workgroup and is scheduled per tile; the other
@@ -1369,6 +1417,14 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.tile_reserve = c->opt_tile_reserve >= 0 ? (uint32_t)c->opt_tile_reserve : (sc->has_pieces ? 24u : 16u);
     a.tile_band_abs = (float)c->opt_band_abs / 64.0f * sc->gm_diag;
     a.tile_prio_div = (uint32_t)c->opt_tile_prio;
+    a.quad_parts = (quad_parts_ok(c, a.n_units) && tile_kernel && c->parts_ok && a.mode != 2 && a.order && a.n_launch && c->qparts_valid) ? 1u : 0u;
+    a.qparts = c->d_qparts; a.qpart_count = c->d_qpcount;
+    // the list's length when the host knows it (a frame tail that ran behind the list's making has copied it to the pinned word; frames of
+    // a standing view keep their order and their list, so frames queued without a host synchronisation between them know it too): a launch
+    // without parts skips the quad kernel and its fork / join, one with parts launches exactly that many waves; else kQuadListCap waves,
+    // the idle ones exit
+    a.quad_known = (a.quad_parts && c->qknown_epoch == c->qlist_epoch) ? (c->qknown_count + 1u) : 0u;
+    if (a.quad_known == 1u) a.quad_parts = 0u; // (known to be empty; the order then holds no code-3 entry either)
     if (tile_kernel) {
         if (!c->ovf_zeroed) CHK(c, hipMemsetAsync(c->d_ovf_next, 0, sizeof(uint32_t), s));
         c->ovf_zeroed = false;
@@ -1441,7 +1497,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     // host word (sizes the pool of the frames to come), and their counter reset for the next frame
     {
         uint32_t* ovf = (rc == GRT_OK) ? a.ovf_next : nullptr;
-        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->ovf_pending ? (uint32_t*)nullptr : c->h_ovf_used);
+        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->ovf_pending ? (uint32_t*)nullptr : c->h_ovf_used, c->d_qpcount, c->h_err + 1);
+        c->tail_qepoch = c->qlist_epoch;
         if (hipGetLastError() == hipSuccess) {
             tail = true;
             if (ovf) {

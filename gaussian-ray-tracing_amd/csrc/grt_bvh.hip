@@ -833,6 +833,51 @@ __global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint
 
 uint32_t order_scratch_bytes() { return ord_scratch_words() * (uint32_t)sizeof(uint32_t); }
 
+// The four-way parts of a launch order as a list of their own, in the order's order (heaviest first): what the quad kernel
+// (grt_render_tile.hip MODE 3) takes, one wave per entry.  The first kQuadListCap of them are listed and re-coded 2 -> 3 in the order, so
+// that the camera-ray kernel leaves them alone; the rest stays as it is.  One workgroup, 1024 entries per round, ranks by ballot + a scan
+// of the 16 waves' counts; it runs behind the ordering kernel, i.e. behind the frame whose costs made the order — not in front of the
+// frame that uses it.
+__global__ __launch_bounds__(1024) void k_quad_list(uint32_t* __restrict__ order, uint32_t n, uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t cap)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t base;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+    if (tid == 0u) base = 0u;
+    __syncthreads();
+    for (uint32_t b = 0; b < n; b += 1024u) {
+        const uint32_t i = b + tid;
+        const uint32_t e = (i < n) ? order[i] : kOrderPad;
+        const bool is = (e != kOrderPad) && ((e >> 30) == 2u);
+        const unsigned long long m = __ballot(is);
+        if (ln == 0u) wsum[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = base;
+        for (uint32_t w = 0; w < wv; w++) off += wsum[w];
+        off += (uint32_t)__popcll(m & ((1ull << ln) - 1ull));
+        if (is && off < cap) {
+            list[off] = e;
+            order[i] = e | (3u << 30);
+        }
+        __syncthreads();
+        if (tid == 0u) { uint32_t t = 0; for (uint32_t w = 0; w < 16u; w++) t += wsum[w]; base += t; }
+        __syncthreads();
+        if (base >= cap) break; // (uniform: every thread reads the same word behind the barrier)
+    }
+    if (tid == 0u) count[0] = min(base, cap);
+}
+
+int quad_part_list(uint32_t* d_order, uint32_t n_entries, uint32_t* d_list, uint32_t* d_count, uint32_t cap, hipStream_t stream, std::string* err)
+{
+    hipLaunchKernelGGL(k_quad_list, dim3(1), dim3(1024), 0, stream, d_order, n_entries, d_list, d_count, std::min(cap, kQuadListCap));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("quad_part_list: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
                            uint32_t multi_min, hipStream_t stream, std::string* err)

@@ -111,6 +111,10 @@ struct RenderArgs {
     float tile_band_abs;     // trees with pieces: absolute floor of band / look-ahead (world units: a multiple of the typical proxy size)
     uint32_t tile_reserve;   // free frontier slots below which leaf steps are forced
     uint32_t tile_prio_div;  // the first 1/div of the cost-sorted launch order runs at raised wave priority (0 = off)
+    uint32_t quad_parts;     // the launch order's four-way parts run on the quad kernel (MODE 3) beside the camera-ray kernel, which skips them
+    const uint32_t* qparts;  // ... those entries of the order, compacted (grt_bvh.hip: k_quad_list), heaviest first
+    const uint32_t* qpart_count; // [0] = how many
+    uint32_t quad_known;     // host's knowledge of that number + 1 (0 = unknown: the grid is the list's capacity)
     float4* ovf_pool;        // window overflow bags: [chunk][entry][lane] x 16 B, one chunk per tile that overflows
     uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
     uint32_t ovf_chunks;     // chunks in the pool
@@ -152,7 +156,8 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
 int launch_render_wave(const RenderArgs& a, bool count, hipStream_t stream, std::string* err);
 int launch_render_stream(const RenderArgs& a, bool count, bool mesh, hipStream_t stream, const LaunchAux* aux,
                          std::string* err);
-int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err);
+int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err, const LaunchAux* aux = nullptr);
+int launch_render_tile_quad(const RenderArgs& a, bool count, hipStream_t stream, std::string* err); // mode 3 (its own TU)
 int launch_render_tile_single(const RenderArgs& a, bool count, hipStream_t stream, std::string* err); // mode 2 (its own TU)
 constexpr int kNumCounters = 8;
 // bits of RenderArgs::err_word
@@ -165,6 +170,10 @@ constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // 
 // of the 1 M scene takes 0.79 of the whole tile's time, a half all of it), or a tile would be split on every other frame only.
 // (A larger factor inflates the split tiles' costs frame over frame until their parts no longer fit the launch.)
 constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
+// code 3 = a four-way part that runs on the QUAD kernel (grt_render_tile.hip MODE 3): k_quad_list (grt_bvh.hip) re-codes the first
+// kQuadListCap four-way entries of an order and lists them for that kernel, whose grid is the list's capacity; what does not fit
+// stays code 2, a part wave of the camera-ray kernel.  (A part's unit is < 2^28, so code 3 | part 3 | unit never equals kOrderPad.)
+constexpr uint32_t kQuadListCap = 4096u;
 constexpr uint32_t kTileResidentWaves = 256u * 16u; // MI355X: 256 CUs x 16 waves of the camera-ray kernel (128 VGPRs, < 10 KB of LDS)
 constexpr uint32_t kCostPartShift = 27u, kCostStepsMask = 0x07FFFFFFu;
 __host__ __device__ inline uint32_t cost_eff(uint32_t c)
@@ -212,6 +221,9 @@ int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
                            uint32_t multi_min, hipStream_t stream, std::string* err);
 uint32_t order_scratch_bytes();
+// the first kQuadListCap four-way part entries of a launch order (n_entries of them incl. padding), in order, listed in d_list and re-coded
+// 2 -> 3 in the order itself; d_count[0] = how many
+int quad_part_list(uint32_t* d_order, uint32_t n_entries, uint32_t* d_list, uint32_t* d_count, uint32_t cap, hipStream_t stream, std::string* err);
 // launch order = units by cost class, heaviest first; also the number of heavy units when d_n_heavy != nullptr
 // (d_zero != nullptr: that array of n cost words is zeroed once the order is made — the costs are consumed)
 int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, uint32_t heavy_cap, uint32_t thr_x2,
@@ -258,6 +270,7 @@ struct grt_ctx {
     int opt_static_sharp = 1;     // GRT_OPT_STATIC_SHARP: a view that stood still for two frames is ordered by its tiles' own costs, not the dilated map
     int opt_order_multi_min = 16384; // GRT_OPT_ORDER_MULTI_MIN: launches of this many tiles and more are ordered by several workgroups
     int opt_mesh_parts = 1;       // GRT_OPT_MESH_PARTS: heavy tiles of a MESH frame's primary stage run as part waves too
+    int opt_quad_parts = 1;       // GRT_OPT_QUAD_PARTS: four-way parts of camera-ray frames (no meshes, no pieces) run on the quad kernel
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit
     bool launch_order_matched = false; // the current launch's order had been made for this very frame (scene, camera, options)
@@ -302,6 +315,11 @@ struct grt_ctx {
     // frame-to-frame scheduling feedback (grt_api.hip: do_launch)
     int opt_feedback = 1;
     uint32_t *d_cost = nullptr, *d_order = nullptr, *d_cost_dil = nullptr, *d_ord_scratch = nullptr;
+    uint32_t *d_qparts = nullptr, *d_qpcount = nullptr; // the order's four-way parts as a list for the quad kernel (allocated with d_order)
+    bool qparts_valid = false;                         // d_qparts was made from the order in d_order
+    uint64_t qlist_epoch = 0, tail_qepoch = ~0ull;     // lists made so far; the one whose length the last frame tail copied to the host
+    uint64_t qknown_epoch = ~0ull;                     // the list whose length the host has read ...
+    uint32_t qknown_count = 0;                         // ... and that length
     int opt_cost_radius = 4; // tiles; 0 = off
     int opt_cold_estimate = 2; // order a frame without previous-frame costs by projected particle counts
     uint32_t cost_cap = 0;

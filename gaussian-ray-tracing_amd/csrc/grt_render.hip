@@ -514,7 +514,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
     // auto: the single-pass streaming kernel (measured faster than the round-based wave kernel from 10k to 3M
     // Gaussians; the two are bit-identical)
     if (streaming && a.mroot == kNoRoot)
-        return tile_kernel ? launch_render_tile(a, count, false, false, stream, err) : launch_render_stream(a, count, false, stream, aux, err);
+        return tile_kernel ? launch_render_tile(a, count, false, 0, stream, err, aux) : launch_render_stream(a, count, false, stream, aux, err);
     // mesh frames: wavefront pipeline (primary segment on the streaming wave kernel, compaction, per-lane bounces)
     if (streaming) {
         if (!a.prec || !a.queue || !a.qcount) {

@@ -61,6 +61,7 @@ constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a la
 constexpr int kBisect = 18;          // most bisection steps of a nearest-k selection (4 / 6 at least)
 constexpr uint32_t kPruneRoom = 32u; // a window bag with less room than this is pruned between steps
 constexpr int kWavesPerSimd = 4;     // waves per SIMD the camera-ray and bundle kernels are compiled for (128 VGPRs)
+constexpr int kWavesQuad = 3;        // ... the quad kernel (MODE 3: per-lane records in the exact test; its launches are bound by their longest wave, not by occupancy)
 // The cost word of a camera-ray tile counts, besides its steps, 2/8 of a step per particle fetched and 12/8 per exact test run: the
 // launch order and the part-wave policy live on that word, and steps alone are a poor proxy of a tile's TIME (a leaf step that carries
 // sixteen ranges through their exact tests and a node step count the same).  Same-box kernel ms with it: C1 0.513 -> 0.472, C2 0.955 ->
@@ -82,6 +83,7 @@ constexpr uint32_t kCostFetch = 2u, kCostTest = 12u;
 #if GRT_TILE_KS == 12
 #define KLAST k11
 #define KPRESS k9 /* a lane holding >= KS-2 keys asks for compositing before the next insert */
+
 #define KROOM k8  /* a lane with room above this slot joins a refill scan it does not need yet */
 #define GRT_KEYS_DECL                                                                                      \
     uint64_t k0 = kKeyInvalid, k1 = kKeyInvalid, k2 = kKeyInvalid, k3 = kKeyInvalid, k4 = kKeyInvalid,     \
@@ -183,6 +185,22 @@ __device__ __forceinline__ uint64_t wave_umin64(uint64_t k)
     const uint32_t lo = (hi == mh) ? (uint32_t)k : 0xFFFFFFFFu;
     const uint32_t ml = __float_as_uint(wave_min(__uint_as_float(lo)));
     return ((uint64_t)mh << 32) | (uint64_t)ml;
+}
+// minimum of 64-bit keys over the four lanes of a quad (lanes 4 q .. 4 q + 3), in every lane of the quad: the high words by two
+// DPP minima, then the low words of the lanes that hold that high word
+__device__ __forceinline__ uint64_t quad_umin64(uint64_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = (uint32_t)(k >> 32);
+    uint32_t mh = min(hi, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
+    mh = min(mh, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh, 0x4E, 0xF, 0xF, true));           // quad_perm [2,3,0,1]
+    const uint32_t lo = (hi == mh) ? (uint32_t)k : 0xFFFFFFFFu;
+    uint32_t ml = min(lo, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true));
+    ml = min(ml, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ml, 0x4E, 0xF, 0xF, true));
+    return ((uint64_t)mh << 32) | (uint64_t)ml;
+#else
+    return k;
+#endif
 }
 __device__ __forceinline__ float lane_value(float v, int l) // v of lane l (l wave-uniform)
 {
@@ -293,11 +311,20 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
 // instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
 template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
-__global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) void k_render_tile(const RenderArgs a)
+__global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWavesQuad : kWavesPerSimd)) void k_render_tile(const RenderArgs a)
 {
-    constexpr bool BUNDLE = MODE != 0, SINGLE = MODE == 2;
-    const uint32_t rank = SINGLE ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u);
-    const uint32_t n_in = BUNDLE ? (SINGLE ? *a.hcount : *a.qcount_in) : 0u; // chunks of the queue / rays of the heavy list
+    constexpr bool BUNDLE = MODE == 1 || MODE == 2, SINGLE = MODE == 2;
+    // MODE 3 (QUAD): camera rays of ONE 4x4 QUADRANT of a heavy tile, lanes = rays x slots: lane 4 r + s carries ray r (16 of them) and
+    // is its slot s.  The exact work turns round as in MODE 2, but four-fold instead of sixty-four-fold: a trip of the exact-test loop
+    // takes FOUR survivors of the leaf step, slot s of every ray tests survivor s (records by vector loads, A (o - mu) per lane) and the hits
+    // go into THAT lane's window — a ray's pending events are the pool of its four windows (+ four bags), its next event the smallest
+    // first key of the quad (two DPP minima).  T, radiance, last key, cut-off and `alive` are per RAY and are kept alike in the four
+    // lanes.  Same arithmetic per event, same order: same bits.  What it is for: a tile whose wave bounds the frame (a rank's share of
+    // a frame, a 256^2 frame) ran as four waves of 16 rays with 48 of 64 lanes idle — each a quarter of the rays but 0.78 of the time,
+    // because the stream of exact tests and inserts is as long for 16 rays as for 64.  Here that stream is a quarter as long.
+    constexpr bool QUAD = MODE == 3;
+    const uint32_t rank = SINGLE ? blockIdx.x : (QUAD ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x, a.swizzle_chunk * 4u));
+    const uint32_t n_in = BUNDLE ? (SINGLE ? *a.hcount : *a.qcount_in) : (QUAD ? a.qpart_count[0] : 0u); // chunks of the queue / rays of the heavy list / parts
     const uint32_t lane = threadIdx.x;
     __shared__ float pl_other[KS * kWG], pl_alpha[KS * kWG];
     __shared__ float pl_col[SINGLE ? 3 * KS * kWG : 1]; // MODE 2: the event's radiance, fetched by the lane that inserted it
@@ -311,6 +338,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
     __shared__ uint2 xch[kWG];       // children on their way to free frontier slots
     __shared__ uint32_t xsel[kBatch]; // refs of the nodes picked for this step
     __shared__ uint2 bag[kBag];      // far part of the frontier: (lambda bits, ref), unordered; its minimum is Fbag
+    __shared__ float4 qstg[QUAD ? 4 * kWG : 1]; // QUAD: the records of a leaf step's survivors (slot = the lane that culled the box), 4 KB
+    (void)qstg;
     __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + kTileWide - 1 siblings
                                  // per wide level below it (tile_stack_fits, grt_internal.h)
     for (uint32_t unit_s = rank;;) { // (one trip; MODE 2: the waves draw the rays of the heavy list from a counter, so
@@ -320,22 +349,30 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
         if (lane == 0u) u_ = atomicAdd(a.hnext, 1u);
         unit_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_);
     }
-    if (BUNDLE && unit_s >= n_in) break; // wave-uniform
+    // (QUAD: wave i takes entry i of the list of four-way parts that k_quad_list compacted from the launch order, heaviest first; the
+    //  grid is the list's capacity — no draw loop: a loop around the whole kernel keeps 75 scalar registers alive across it)
+    if ((BUNDLE || QUAD) && unit_s >= n_in) break; // wave-uniform
     Cnt c, w;
     (void)w;
     // camera rays: an entry of the launch order may name a PART of a heavy tile (grt_internal.h: kOrderUnitMask; grt_bvh.hip:
     // k_cost_order_parts) — the wave then traces the tile's upper / lower 4 rows, or one of its 4x4 quadrants, and the other
     // lanes carry no ray; entries past the last one are padding
-    const uint32_t ue = (a.order && !BUNDLE) ? a.order[rank] : unit_s;
-    if (!BUNDLE && a.order && (ue & kOrderUnitMask) >= a.n_units) break; // padding (kOrderPad), or anything that is not a tile of this launch
+    const uint32_t ue = QUAD ? a.qparts[unit_s] : ((a.order && !BUNDLE) ? a.order[rank] : unit_s);
+    if (!BUNDLE && (a.order || QUAD) && (ue & kOrderUnitMask) >= a.n_units) break; // padding (kOrderPad), or anything that is not a tile of this launch
+    // code 3 = a four-way part that k_quad_list handed to the quad kernel (MODE 3): not this kernel's when that kernel is launched
+    // beside it (a.quad_parts); else a four-way part like any other
+    if (MODE == 0 && a.quad_parts && (ue >> 30) == 3u) break;
     const uint32_t unit = BUNDLE ? ue : (ue & kOrderUnitMask);
     // (lane = 8 row + column: bit 5 = lower half of the tile, bit 2 = right half; formed from `ue` where it is needed — at the
     //  ray set-up and at the pixel write — so that nothing but `ue` lives across the passes)
-#define GRT_IN_PART (BUNDLE || (ue >> 30) == 0u || (((ue >> 30) == 1u ? (lane >> 5) : (((lane >> 5) << 1) | ((lane >> 2) & 1u))) == ((ue >> 28) & 3u)))
+#define GRT_IN_PART (BUNDLE || QUAD || (ue >> 30) == 0u || /* (codes 1, 2: halves, quarters as part waves of this kernel) */ (((ue >> 30) == 1u ? (lane >> 5) : (((lane >> 5) << 1) | ((lane >> 2) & 1u))) == ((ue >> 28) & 3u)))
     // the heaviest tiles of the previous frame (the head of the cost-sorted order) bound the frame: they issue first
     if (!BUNDLE && a.order && a.tile_prio_div && rank < gridDim.x / a.tile_prio_div) __builtin_amdgcn_s_setprio(2);
+    if (QUAD) __builtin_amdgcn_s_setprio(3); // (the quad kernel's waves ARE the frame's critical path: they issue first on their SIMD)
     const uint32_t blk = unit >> 2, wave = unit & 3u;
-    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    // (QUAD: ray r = lane / 4 is pixel (r % 4, r / 4) of quadrant `part`: bit 0 = right half, bit 1 = lower half of the tile)
+    const uint32_t tx8 = QUAD ? (((ue >> 28) & 1u) * 4u + ((lane >> 2) & 3u)) : (lane & 7u), ty8 = QUAD ? (((ue >> 29) & 1u) * 4u + (lane >> 4)) : (lane >> 3);
+    const uint32_t lx = (wave & 1u) * 8u + tx8, ly = (wave >> 1) * 8u + ty8;
     uint32_t px = 0, py = 0;
     size_t out_idx = 0;
     bool in_frame = false;
@@ -363,8 +400,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
         in_frame = (px < a.p.width) && (py < a.p.height);
         out_idx = ((size_t)j * a.tile_h + oy) * a.tile_w + ox;
     }
-    const bool write = BUNDLE ? (in_frame && (!SINGLE || lane == 0u)) : (in_frame || (a.mode == 1));
-    const bool tally = !SINGLE || lane == 0u; // per-ray counters: once per ray
+    const bool tally = SINGLE ? (lane == 0u) : (!QUAD || (lane & 3u) == 0u); // per-ray counters (and the pixel): once per ray
+    const bool write = BUNDLE ? (in_frame && tally) : ((in_frame || (a.mode == 1)) && tally);
     const f3 nU = mk3(-a.p.U[0], -a.p.U[1], -a.p.U[2]), nV = mk3(-a.p.V[0], -a.p.V[1], -a.p.V[2]);
     const f3 W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
     f3 o = mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]); // wave-uniform origin (camera rays); per lane when BUNDLE
@@ -383,7 +420,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
         else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
     }
     have_ray = have_ray && GRT_IN_PART;
-    if (COUNT && have_ray && !MESH) c.rays++;
+    if (COUNT && have_ray && !MESH && tally) c.rays++;
     have_ray = have_ray && (length3(d) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
     float seg_tmax = a.p.t_max;
     uint32_t pflags = 0;
@@ -555,6 +592,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
         uint32_t dbg_n = 0, dbg_m = 0;
 #endif
         uint32_t chunk = kNoRoot; // this tile's chunk of the overflow pool (taken at the first window overflow)
+        // (QUAD: a ray's four bags TOGETHER hold what one bag of the camera-ray kernel holds.  The capacity is a cut-off, not just room:
+        //  a ray whose bag is full stops wanting what lies beyond, the tile's reach shrinks with it and the frontier stays clear of far
+        //  entries — with four full-size bags a quadrant of a cluster core went on for 242 steps where the part wave took 164)
+        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : a.ovf_entries, prune_room = QUAD ? kPruneRoom / 4u : kPruneRoom;
         const uint32_t ready_min = SINGLE ? 1u : a.tile_ready_min; // lanes with a final event before a compositing sweep starts
         // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
         const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;
@@ -732,9 +773,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                 // any later pass (a lane came back: its cut-off did fall short).  Behind a moving front the arrivals are
                 // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
-                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + kPruneRoom >= a.ovf_entries);
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + prune_room >= bag_cap);
                     if (wave_any(pr_)) { // wave-uniform, rare
                         bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
+                        if (QUAD) lost = quad_umin64(lost);
                         lim_dirty = true;
                     }
                 }
@@ -777,15 +819,19 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                     // key: t < F <=> key < F's bits << 32, both non-negative), the lane's bag minimum and its cut-off.  The limit
                     // changes once per trip of the outer loop (and after a refill); the test below runs once per compositing step
                     // and once more per trip: one 64-bit compare instead of four compares (k0 = ~0, a free slot, is never below it).
+                    // (QUAD: the RAY's next event is the smallest first key of its four windows, its limit the smallest of the four lanes' — q0_ and
+                    //  limk_ are alike in the lanes of a quad, and so is everything derived from them)
                     const uint64_t fkey_ = (uint64_t)__float_as_uint(F) << 32;
                     uint64_t limk_ = (bagmin < lost) ? bagmin : lost;
+                    if (QUAD) limk_ = quad_umin64(limk_);
                     limk_ = (fkey_ < limk_) ? fkey_ : limk_;
                     while (true) {
-                        bool can_ = alive & (k0 < limk_);
-                        uint64_t cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
+                        uint64_t q0_ = QUAD ? quad_umin64(k0) : k0;
+                        bool can_ = alive & (q0_ < limk_);
+                        uint64_t cm_ = wave_ballot(alive) & wave_ballot(q0_ < limk_);
                         // a lane whose next final event sits in its bag needs a refill before it can go on
                         const bool need = bags && alive && (nb != 0u) && !can_ && (key_t(bagmin) < F) && (bagmin < lost) &&
-                                          ((k0 == kKeyInvalid) || (k0 >= bagmin));
+                                          ((q0_ == kKeyInvalid) || (q0_ >= bagmin));
                         const uint64_t nm_ = bags ? wave_ballot(need) : 0ull;
                         if (!(cm_ | nm_)) break;
                         // A sweep starts — and goes on — while enough lanes can take part: half of the WANTING lanes, at most
@@ -797,7 +843,12 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                         // third of the 100 k frame.
                         if (!done) {
                             const uint32_t rmin_ = min(ready_min, max(1u, (nact_cur + 1u) >> 1));
-                            const bool go_ = ((uint32_t)__popcll(cm_ | nm_) >= rmin_) ||
+                            // (QUAD: the count is in lanes, four per ray — a ray that waits for the refill of ONE of its windows counts as a ray,
+                            //  or the last ray of a quadrant, 1 lane against a threshold of 2, would wait for the end of the pass)
+                            uint64_t nmq_ = nm_;
+                            if (QUAD && nm_) { nmq_ |= (nmq_ & 0xAAAAAAAAAAAAAAAAull) >> 1; nmq_ |= (nmq_ & 0x5555555555555555ull) << 1;
+                                               nmq_ |= (nmq_ & 0xCCCCCCCCCCCCCCCCull) >> 2; nmq_ |= (nmq_ & 0x3333333333333333ull) << 2; }
+                            const bool go_ = ((uint32_t)__popcll(cm_ | nmq_) >= rmin_) ||
                                              wave_any(can_ && ((KPRESS != kKeyInvalid) || (T < kSweepEagerT)));
                             if (!go_) break;
                         }
@@ -852,23 +903,31 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                             //  the arms of a structurised if / else keep BOTH versions of the window alive, 27 register copies
                             //  per compositing step)
                             limk_ = (bagmin < lost) ? bagmin : lost;
+                            if (QUAD) limk_ = quad_umin64(limk_);
                             limk_ = (fkey_ < limk_) ? fkey_ : limk_;
-                            can_ = alive & (k0 < limk_);
-                            cm_ = wave_ballot(alive) & wave_ballot(k0 < limk_);
+                            q0_ = QUAD ? quad_umin64(k0) : k0;
+                            can_ = alive & (q0_ < limk_);
+                            cm_ = wave_ballot(alive) & wave_ballot(q0_ < limk_);
                         }
                         if (!cm_) continue;
                         GRT_D(hit_evals, 1)
-                        const uint64_t ek = k0;
+                        const uint64_t ek = q0_;
                         const uint32_t cell = (uint32_t)(ek & kCellMask);
                         const uint32_t id = skey_id(ek);
                         float ea = 0.0f, eo = INFINITY, T_old = 0.0f;
                         bool blend_ = false;
                         float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        // QUAD: the event sits in ONE of the ray's four windows (a particle is tested by one slot per pass: the keys of a ray
+                        // are distinct); that lane pops it, all four read its payload cell and take the same compositing step
+                        const bool own_ = !QUAD || (k0 == q0_);
+                        const uint64_t ownm_ = QUAD ? (cm_ & wave_ballot(k0 == q0_)) : cm_;
+                        uint32_t ol_ = lane; // the lane whose window holds the event
+                        if (QUAD) ol_ = (lane & 60u) + (uint32_t)__builtin_ctz(((uint32_t)(ownm_ >> (lane & 60u)) & 15u) | 16u);
                         if (can_) { // payload from LDS and (degree 0) the colour, both in flight while the window is popped
-                            ea = PL_ALPHA(cell); eo = PL_OTHER(cell);
+                            ea = QUAD ? pl_alpha[cell * kWG + ol_] : PL_ALPHA(cell); eo = QUAD ? pl_other[cell * kWG + ol_] : PL_OTHER(cell);
                             if (!SH) cc = a.color0[id];
                         }
-                        SLOT_SHIFT_ALL(cm_)
+                        SLOT_SHIFT_ALL(ownm_)
 #ifdef GRT_TILE_CHECK
                         if (can_ && a.outf && lane == GRT_TILE_CHECK_LANE && dbg_n < 1900u) { // event log of one lane
                             a.outf[dbg_n * 3] = key_t(ek); a.outf[dbg_n * 3 + 1] = (float)(id * 2u + ((((uint32_t)ek) >> 5) & 1u)); a.outf[dbg_n * 3 + 2] = T;
@@ -880,7 +939,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                         const bool dup_ = PIECES && can_ && ((ek | kCellMask) == last_key);
                         const uint64_t dupm_ = PIECES ? wave_ballot((ek | kCellMask) == last_key) : 0ull;
                         if (can_ && !dup_) { // shaders/tracer.cuh:352-367
-                            if (COUNT) c.hit_evals++;
+                            if (COUNT && (!QUAD || own_)) c.hit_evals++;
                             last_key = ek | kCellMask; // nothing with the same (t, id, exit) can compare above it
                             if (a.p.alpha_min < ea) {
                                 if (!SH) { // degree 0: the colour load is still in flight; its use waits until the re-key is done
@@ -898,10 +957,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                         }
                         // an entry whose exit lies inside the segment is re-keyed to its exit event and keeps its
                         // payload cell, otherwise the cell is released
-                        const bool rekey = can_ && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
+                        const bool rekey = can_ && own_ && !dup_ && ((((uint32_t)ek) & 32u) == 0u) && (eo < t_hi);
                         const uint64_t nk = rekey ? (mk_skey(eo, id, 1) | (uint64_t)cell) : kKeyInvalid;
-                        pmask = (can_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
-                        const uint64_t rkm_ = cm_ & ~dupm_ & vote_eq_u32(((uint32_t)ek) & 32u, 0u) & vote_lt_f32(eo, t_hi);
+                        pmask = (can_ && own_ && !rekey) ? (pmask & ~(1u << cell)) : pmask;
+                        const uint64_t rkm_ = ownm_ & ~dupm_ & vote_eq_u32(((uint32_t)ek) & 32u, 0u) & vote_lt_f32(eo, t_hi);
                         if (rkm_) { // wave-uniform branch
                             if (rekey) PL_OTHER(cell) = INFINITY;
                             SLOT_INSERT(nk) // a slot was just freed: it fits
@@ -1018,6 +1077,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                     b0 = src[0];
                     b1 = src[1];
                 }
+                // QUAD, leaf step: the candidates' RECORDS are asked for together with their boxes — speculatively, for the ones the cull
+                // will drop too: a second, dependent round trip to memory per leaf step is what bounds a heavy tile's wave (a vector load
+                // returns after ~0.5 us; the first form of this kernel, which fetched the survivors' records behind the cull, ran a
+                // 256^2 frame in 0.67 ms instead of 0.46)
+                float4 rq0 = b0, rq1 = b0, rq2 = b0, rq3 = b0;
+                if (QUAD && leaf_step && cv) {
+                    const float4* rp = a.rec + (size_t)(first + j) * 4;
+                    rq0 = rp[0]; rq1 = rp[1]; rq2 = rp[2]; rq3 = rp[3];
+                }
                 const uint32_t cref = leaf_step ? (first + j) : __float_as_uint(b0.w); // particle index / child ref
                 const bool valid = cv && (cref != kNoRoot);
                 if (COUNT && valid) c.node_visits++; // one 32-B child box per lane
@@ -1082,7 +1150,11 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
 
                 if (leaf_step) {
                     GRT_D(fetches, 1)
-                    if (MODE == 0) work += kCostFetch * (uint32_t)__popcll(wm);
+                    if (MODE == 0 || QUAD) work += kCostFetch * (uint32_t)__popcll(wm);
+                    if (QUAD && wm) { // the survivors' records to LDS, each by the lane that culled its box: slot s of every ray reads survivor s's
+                        if (want) { qstg[lane * 4u] = rq0; qstg[lane * 4u + 1u] = rq1; qstg[lane * 4u + 2u] = rq2; qstg[lane * 4u + 3u] = rq3; }
+                        wave_fence();
+                    }
                     // ---- exact tests of the surviving particles, all lanes = rays (grt_render_stream's arithmetic) ----
                     bool trip = wm != 0ull; // MODE 2: ONE trip, lanes = particles
                     const uint64_t alivem_ = wave_ballot(alive); // (nothing in this loop changes it)
@@ -1099,6 +1171,22 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                             }
                             if (COUNT) c.fetches += 4u * (uint32_t)__popcll(wm);
                             wm = 0ull;
+                        } else if (QUAD) { // up to four survivors at once: slot s of every ray fetches and tests survivor s
+                            const uint32_t p0_ = (uint32_t)__builtin_ctzll(wm);
+                            wm = clear_bit64(wm, p0_);
+                            uint32_t p1_ = p0_, p2_ = p0_, p3_ = p0_, nsv = 1u; // (the survivors' lanes = their slots of the staged records)
+                            if (wm) {
+                                p1_ = (uint32_t)__builtin_ctzll(wm); wm = clear_bit64(wm, p1_); nsv = 2u;
+                                if (wm) {
+                                    p2_ = (uint32_t)__builtin_ctzll(wm); wm = clear_bit64(wm, p2_); nsv = 3u;
+                                    if (wm) { p3_ = (uint32_t)__builtin_ctzll(wm); wm = clear_bit64(wm, p3_); nsv = 4u; }
+                                }
+                            }
+                            const uint32_t sl_ = lane & 3u;
+                            const uint32_t sv_ = (sl_ == 0u) ? p0_ : ((sl_ == 1u) ? p1_ : ((sl_ == 2u) ? p2_ : p3_));
+                            act_ = alive && (sl_ < nsv);
+                            r0 = qstg[sv_ * 4u]; r1 = qstg[sv_ * 4u + 1u]; r2 = qstg[sv_ * 4u + 2u]; r3 = qstg[sv_ * 4u + 3u];
+                            if (COUNT) c.fetches += 4u * nsv;
                         } else {
                             const uint32_t b = (uint32_t)__builtin_ctzll(wm);
                             wm = clear_bit64(wm, b);
@@ -1118,15 +1206,23 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                         A.a[0] = r1.x; A.a[1] = r1.y; A.a[2] = r1.z;
                         A.a[3] = r2.x; A.a[4] = r2.y; A.a[5] = r2.z;
                         A.a[6] = r3.x; A.a[7] = r3.y; A.a[8] = r3.z;
-                        // A (o - mu): from the eye record (wave-uniform), or per lane for a bundle
-                        const f3 o_g = BUNDLE ? matvec(A, sub3(o, mu)) : mk3(e0.x, e0.y, e0.z);
-                        const float cc_ = BUNDLE ? proxy_sphere_cc(o_g, r0.w) : e0.w;
+                        // A (o - mu): from the eye record (wave-uniform), or per lane for a bundle / a quad's own particle (the very operation
+                        // sequence the eye records were made with: the same bits)
+                        const f3 o_g = (BUNDLE || QUAD) ? matvec(A, sub3(o, mu)) : mk3(e0.x, e0.y, e0.z);
+                        const float cc_ = (BUNDLE || QUAD) ? proxy_sphere_cc(o_g, r0.w) : e0.w;
                         const f3 d_g = matvec(A, d);
                         {   // conservative sphere pre-test (proxy_sphere_maybe_pre) as lane masks
                             const float b_ = dot3(o_g, d_g), aa_ = dot3(d_g, d_g);
                             const uint64_t m_ = (wave_ballot(cc_ <= 0.0f) | wave_ballot(b_ * b_ * (1.0f + 4e-6f) >= aa_ * cc_)) &
-                                                (SINGLE ? wave_ballot(act_) : alivem_);
+                                                ((SINGLE || QUAD) ? wave_ballot(act_) : alivem_);
                             if (!m_) continue;
+                            // (QUAD: the cost word counts a trip's particles as the camera-ray kernel counts them — those some lane can touch —
+                            //  so that a tile costs the same word on either kernel and the launch order splits the same tiles)
+                            if (QUAD) {
+                                uint32_t f_ = (uint32_t)m_ | (uint32_t)(m_ >> 32);
+                                f_ |= f_ >> 16; f_ |= f_ >> 8; f_ |= f_ >> 4;
+                                work += kCostTest * (uint32_t)__builtin_popcount(f_ & 15u);
+                            }
                         }
                         if (COUNT && act_) c.proxy_tests++;
                         if (MODE == 1) work += 2u;
@@ -1134,7 +1230,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                         GRT_D(proxy_tests, 1)
                         float te, tx;
                         float pa[10]; // slab_project(o_g)
-                        if (BUNDLE) {
+                        if (BUNDLE || QUAD) {
                             slab_project(o_g, pa);
                         } else {
                             pa[0] = e1.x; pa[1] = e1.y; pa[2] = e1.z; pa[3] = e1.w; pa[4] = e2.x; pa[5] = e2.y; pa[6] = e2.z;
@@ -1177,7 +1273,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                                     chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u);
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < a.ovf_entries) && (dk < lost);
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < bag_cap) && (dk < lost);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
                                     a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
@@ -1189,6 +1285,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
                                 lost = (gone && (dk < lost)) ? dk : lost;
                                 if (SINGLE) lost = wave_umin64(lost);
                                 else bags = true;
+                                if (QUAD) lost = quad_umin64(lost); // the cut-off is the RAY's: an event one of its windows lost bounds all four
                                 if (wave_any(gone)) lim_dirty = true;
                             }
                             KLAST = (take && full) ? kKeyInvalid : KLAST;
@@ -1270,7 +1367,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
             // (max_iters <= kCostStepsMask - 1: grt_set_option; a stack-guard give-up has its own bit and is not a step watchdog)
             const bool over = watchdog && !(iters & kCostStackBit);
             cw = over ? max(cw, a.max_iters + 1u) : min(cw, a.max_iters);
-            atomicMax(&a.cost[ue & kOrderUnitMask], (iters & (kCostStackBit | kCostStallBit)) | cw | ((ue >> 30) << kCostPartShift));
+            atomicMax(&a.cost[ue & kOrderUnitMask], (iters & (kCostStackBit | kCostStallBit)) | cw | (min(ue >> 30, 2u) << kCostPartShift));
         }
     }
     if (MODE == 1 && aborted) { // wave-uniform: nothing is written, the chunk's rays join the heavy list
@@ -1407,7 +1504,27 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : kWavesPerSimd) v
 } // namespace
 
 typedef void (*TileKernel)(const RenderArgs);
-#ifdef GRT_TILE_SINGLE_TU
+#ifdef GRT_TILE_QUAD_TU
+// ---- this translation unit (grt_render_tile_quad.hip) holds the quad mode alone (MODE 3: the four-way parts of heavy tiles,
+//      lanes = rays x slots) ----
+int launch_render_tile_quad(const RenderArgs& a, bool count, hipStream_t stream, std::string* err)
+{
+    if (!a.qparts || !a.qpart_count) return GRT_OK;
+    const bool sh = a.p.sh_degree_max > 0;
+    RenderArgs b = a;
+    b.heavy_role = 0;
+    TileKernel k = count ? (sh ? k_render_tile<true, true, false, 3, false> : k_render_tile<true, false, false, 3, false>)
+                         : (sh ? k_render_tile<false, true, false, 3, false> : k_render_tile<false, false, false, 3, false>);
+    // (one wave per entry of the list when the host knows its length, else per entry it can hold: the waves past its end exit at once)
+    hipLaunchKernelGGL(k, dim3(a.quad_known ? a.quad_known - 1u : kQuadListCap), dim3(kWG), 0, stream, b);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (err) *err = std::string("k_render_tile (quad parts) launch: ") + hipGetErrorString(e);
+        return GRT_ERR_HIP;
+    }
+    return GRT_OK;
+}
+#elif defined(GRT_TILE_SINGLE_TU)
 // ---- this translation unit (grt_render_tile_single.hip) holds the one-ray-per-wave mode alone, compiled with an 8-key
 //      window: its LDS per wave is 14 KB instead of 19 KB (the window's payload cells carry the events' radiance there) and
 //      it fits 168 VGPRs, so 11 waves per CU are resident instead of 8.  The mode waits on memory for 46 % of its wave
@@ -1447,7 +1564,7 @@ static TileKernel pick_tile(bool count, bool sh, bool mesh, int mode, bool piece
 // mode 0: camera rays (mesh = stage 2 of the wavefront pipeline: up to their mesh hit); mode 1: stage 3, one wave per
 // chunk of a.queue_in (grid = the most chunks there can be: one per 8x8 tile of the launch); mode 2: one wave per ray of
 // the heavy list, a resident grid drawing from it (grt_render_tile_single.hip)
-int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err)
+int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hipStream_t stream, std::string* err, const LaunchAux* aux)
 {
     if (a.n_blocks == 0) return GRT_OK;
     if (a.root_ref != kNoRoot && (!a.pbox || (!(a.root_ref & kLeafBit) && !a.qnodes) || (mode == 0 && !a.erec))) {
@@ -1466,7 +1583,33 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
     // mode 0: one wave per entry of the launch order (tiles + the parts of split tiles, padded) or per tile; mode 1: one wave per
     // chunk the queue can hold (launch_render passes it as n_launch)
     const uint32_t grid = ((mode == 1 || a.order) && a.n_launch) ? a.n_launch : a.n_blocks * 4u;
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, stream, b);
+    // The four-way parts of heavy tiles run on the quad kernel BESIDE this launch (camera rays without meshes or pieces).  The quad
+    // kernel goes on the frame's own stream, this kernel on the second one behind a fork event: the parts are the frame's longest waves
+    // and must be dispatched FIRST — launched the other way round (or with the second stream at high priority) they found the machine
+    // already full of this kernel's waves and waited 0.2-0.4 ms for registers (a 720p frame: 0.76 -> 0.9-1.0 ms).
+    const bool quad = mode == 0 && !mesh && a.quad_parts && a.order && a.n_launch && a.qparts && a.qpart_count && aux && aux->aux && aux->fork && aux->join;
+    b.quad_parts = quad ? 1u : 0u;
+    hipStream_t main_stream = stream;
+    if (quad) {
+        hipError_t eq = hipEventRecord(aux->fork, stream);
+        if (eq == hipSuccess) eq = hipStreamWaitEvent(aux->aux, aux->fork, 0);
+        if (eq != hipSuccess) {
+            if (err) *err = std::string("tile kernel: fork to the second stream: ") + hipGetErrorString(eq);
+            return GRT_ERR_HIP;
+        }
+        const int rq = launch_render_tile_quad(b, count, stream, err);
+        if (rq != GRT_OK) return rq;
+        main_stream = aux->aux;
+    }
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, main_stream, b);
+    if (quad) {
+        hipError_t eq = hipEventRecord(aux->join, aux->aux);
+        if (eq == hipSuccess) eq = hipStreamWaitEvent(stream, aux->join, 0);
+        if (eq != hipSuccess) {
+            if (err) *err = std::string("tile kernel: join of the second stream: ") + hipGetErrorString(eq);
+            return GRT_ERR_HIP;
+        }
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("k_render_tile launch: ") + hipGetErrorString(e);

@@ -50,6 +50,7 @@ ARCH = os.environ.get("GRT_ARCH", "gfx950")
 #
 # The repair is deliberately narrow: offenders move behind the restore only when ALL of them are VGPR spill STORES
 # (`scratch_store_dword* ... ; N-byte Folded Spill`: the value of the lanes that skipped the branch must reach the slot too)
+# — at a rule-(A) label also rematerialised constants (`v_mov_b32 vN, const`: nothing there can be a then-branch's phi copy) —
 # and nothing that stays between a moved store and the restore waits on the vector-memory counter or names a moved register
 # (s_waitcnt vmcnt / v_readlane / v_writelane: their order against the store would change).  Anything else — a reload, a
 # rematerialised constant (a then-branch's phi copy looks the same), a dependence — FAILS the build with the snippet.
@@ -62,6 +63,8 @@ SPILL_STORE = re.compile(r"^scratch_store_dword(x[234])?\b.*;\s*\d+-byte Folded 
 RA_MADE = re.compile(r"^(scratch_(store|load)_dword(x[234])?\b.*;\s*\d+-byte Folded (Spill|Reload)|"
                      r"v_mov_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|v_mov_b64_e32 v\[\d+:\d+\], (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|"
                      r"v_bfrev_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9]+)\s*$)")
+CONST_MOVE = re.compile(r"^(v_mov_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|v_mov_b64_e32 v\[\d+:\d+\], (0x[0-9a-fA-F]+|-?[0-9.]+)\s*$|"
+                        r"v_bfrev_b32_e32 v\d+, (0x[0-9a-fA-F]+|-?[0-9]+)\s*$)")
 # offenders of rule (A) accepted as they stand, by opcode, each with its reason (none today)
 WHITELIST = {}
 
@@ -140,18 +143,23 @@ class Asm:
         """None when the offenders in front of the restore at line i may simply move behind it, else the reason why not."""
         L = self.L
         moved = set()
+        # (at the target of an s_cbranch_execz — rule (A) — nothing in front of the restore can be a then-branch's own work, so a
+        #  rematerialised constant there is the allocator's too and moves with the stores; elsewhere it could be a phi copy: refused)
+        m = LABEL.match(L[self.block_top(i)].strip())
+        at_join = bool(m) and m.group(1) in self.execz_targets
         for k in off:
             u = L[k].strip()
-            if not SPILL_STORE.match(u):
+            if not SPILL_STORE.match(u) and not (at_join and CONST_MOVE.match(u)):
                 return f"not a VGPR spill store: {u}"
             moved |= vgprs_of(u)
-        for k in range(off[0] + 1, i):  # what stays between the first moved store and the restore
+        stores = [k for k in off if SPILL_STORE.match(L[k].strip())]
+        for k in range(off[0] + 1, i):  # what stays between the first moved instruction and the restore
             if k in off:
                 continue
             u = L[k].strip()
             if not u or u.startswith(";") or u.startswith("."):
                 continue
-            if re.match(r"^s_waitcnt\b.*vmcnt", u):
+            if stores and k > stores[0] and re.match(r"^s_waitcnt\b.*vmcnt", u):
                 return f"an s_waitcnt on the vector-memory counter stays between a moved store and the restore: {u}"
             if vgprs_of(u) & moved:
                 return f"an instruction that stays between a moved store and the restore names a moved register: {u}"

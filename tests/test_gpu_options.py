@@ -76,6 +76,7 @@ def test_heavy_tiles_as_part_waves_give_the_same_frame():
     acts, p, sc, op, _ = make_scene(31, 30000, 200, 136, scale_boost=0.45)
     tr = grt.Tracer(0)
     tr.upload(acts)
+    tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)  # the frame of whole tiles
     ref8, reff = tr.render(p, want_f32=True)
     ref8, reff = ref8.clone(), reff.clone()
     tr.set_option(grt.OPT_COUNTERS, 1)
@@ -83,7 +84,11 @@ def test_heavy_tiles_as_part_waves_give_the_same_frame():
     c0 = tr.counters()
     tr.set_option(grt.OPT_COUNTERS, 0)
     w8 = torch.zeros_like(ref8)
-    for v2, v4, vl in ((1, 0, 0), (1, 1, 0), (0, 1, 0), (10, 40, 0), (20, 60, 50), (0, 70, 75), (5, 5, 100)):
+    # (the four-way parts on the quad kernel — GRT_OPT_QUAD_PARTS = 2: whatever the launch's size; by default only launches of 2048 to 12 288
+    #  tiles use it — and as part waves of the camera-ray kernel; 64: the quad kernel takes 64 parts at most, the rest stay part waves)
+    for quad, v2, v4, vl in ((2, 1, 0, 0), (2, 1, 1, 0), (2, 0, 1, 0), (64, 0, 1, 0), (0, 0, 1, 0), (2, 10, 40, 0), (0, 10, 40, 0), (2, 20, 60, 50), (2, 0, 70, 75),
+                             (0, 0, 70, 75), (2, 5, 5, 100), (1, 5, 5, 100)):
+        tr.set_option(grt.OPT_QUAD_PARTS, quad)
         tr.set_option(grt.OPT_TILE_PARTS2_PCT, v2)
         tr.set_option(grt.OPT_TILE_PARTS4_PCT, v4)
         tr.set_option(grt.OPT_TILE_PARTS_LOAD_PCT, vl)
@@ -316,3 +321,55 @@ def test_assemble_tiles_equals_the_torch_unpermute():
     with pytest.raises(grt.GrtError):
         t.assemble_tiles(g, world, 1, T, W, H, out)  # world x max_cnt tiles do not cover the frame
     t.close()
+
+
+def test_quad_parts_every_tile_under_window_overflow_sh_and_fisheye():
+    """GRT_OPT_QUAD_PARTS with thresholds that send EVERY tile to the quad kernel (one 4x4 quadrant per wave, lanes = rays x slots),
+    where its machinery is under load: a camera inside the densest cluster (every window overflows into its bag, bags are pruned,
+    rays go again), SH degree 2, a fisheye frame with rayless pixels, a moving camera (costs of one view order the next), counters
+    on (the instrumented instantiation).  The frame must be the frame of whole tiles, byte for byte; consumed hits per ray equal."""
+    W, H = 160, 128
+    acts, p0, sc, op0, center = make_scene(61, 60000, W, H, scale_boost=1.3)
+    h, edges = np.histogramdd(acts["pos"], bins=24, range=[(-1.5, 1.5)] * 3)
+    i = np.unravel_index(np.argmax(h), h.shape)
+    eye = tuple(float((edges[k][i[k]] + edges[k][i[k] + 1]) / 2) for k in range(3))
+    views = [("dense core", grt.default_params(W, H, center, eye=eye)), ("default", p0)]
+    psh = grt.default_params(W, H, center); psh.sh_degree_max = 2
+    views.append(("sh2", psh))
+    pfe = grt.default_params(W, H, center, eye=(0.3, 0.2, 1.1)); pfe.mode_fisheye = 1
+    views.append(("fisheye", pfe))
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    for name, p in views:
+        tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)
+        tr.set_option(grt.OPT_COUNTERS, 1)
+        ref8, reff = tr.render(p, want_f32=True)
+        ref8, reff = ref8.clone(), reff.clone()
+        c0 = tr.counters()
+        tr.set_option(grt.OPT_TILE_PARTS4_PCT, 1)
+        tr.set_option(grt.OPT_TILE_PARTS_LOAD_PCT, 0)
+        for quad in (2, 0):
+            tr.set_option(grt.OPT_QUAD_PARTS, quad)
+            for counters in (1, 0):
+                tr.set_option(grt.OPT_COUNTERS, counters)
+                for it in range(3):
+                    a8, af = tr.render(p, want_f32=True)
+                    tr.check()
+                    assert (a8 == ref8).all() and (af == reff).all(), (name, quad, counters, it)
+                if counters:
+                    c1 = tr.counters()
+                    for k in ("rays", "segments", "hit_evals"):
+                        assert c1[k] == c0[k], (name, quad, k)
+                    assert c1["stall_exits"] == 0
+    # a camera that moves: every frame is ordered (and split) by another view's costs
+    tr.set_option(grt.OPT_QUAD_PARTS, 2)
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    for j in range(6):
+        pm = grt.default_params(W, H, center, eye=(0.4 * j, 0.1 * j, 3.0 - 0.3 * j))
+        tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)
+        r8 = tr.render(pm)[0].clone()
+        tr.set_option(grt.OPT_TILE_PARTS4_PCT, 1)
+        for it in range(2):
+            assert (tr.render(pm)[0] == r8).all(), (j, it)
+    tr.check()
+    tr.close(); sc.close()
