@@ -1056,18 +1056,25 @@ static int fill_common(grt_ctx* c, const grt_params* p, RenderArgs* a)
 // which is what makes last frame's cost a good predictor; the first frame (or any change of size / mode) runs in
 // the default XCD-chunked order.
 // launch order of the units from the costs the last frame left in d_cost (dilated for full-frame launches)
-static uint32_t parts_extra_cap(uint32_t n_units) { return n_units / 4u + 64u; } // launch entries beyond one per tile
+// launch entries beyond one per tile (the parts of split tiles): a quarter of the tiles — and, for a launch that does not fill the
+// machine, whatever fills it (a 256^2 frame is 1024 tiles on 4096 wave slots, its tiles' costs lie close together, and with room for
+// 106 split tiles the 107th, whole, bounded the frame)
+static uint32_t parts_extra_cap(uint32_t n_units)
+{
+    const uint32_t base = n_units / 4u + 64u;
+    return n_units < kTileResidentWaves ? std::max(base, std::min(3u * n_units, kTileResidentWaves - n_units)) : base;
+}
 // four-way parts on the quad kernel: camera rays without meshes or pieces (that kernel has no mesh stage and no piece bookkeeping; such
 // frames keep part waves of the camera-ray kernel)
-// — and launches that the parts of their heaviest tiles BOUND: between half and three times the machine's resident waves (measured,
-// profiles/r05_experiments_log.md 4: a rank's share of a 1080p frame, 4050 / 8100 tiles, 0.77 -> 0.55 / 0.75 -> 0.61 ms; a 256^2 frame
-// of 1024 tiles is bound by how its thousand waves spread over the machine and a 720p frame of 14 400 by its total work: both lose
-// 5 % to the second kernel).  GRT_OPT_QUAD_PARTS = 2 forces it on whatever the size (tests).
+// — and launches that the parts of their heaviest tiles BOUND: up to three times the machine's resident waves (measured,
+// profiles/r05_experiments_log.md 4: a 256^2 frame, 1024 tiles, 0.46 -> 0.27 ms; a rank's share of a 1080p frame, 4050 / 8100 tiles,
+// 0.77 -> 0.55 / 0.75 -> 0.61 ms; a 720p frame of 14 400 tiles is bound by its total work and loses 5 % to the second kernel).
+// GRT_OPT_QUAD_PARTS = 2 forces it on whatever the size (tests).
 static bool quad_parts_ok(const grt_ctx* c, uint32_t n_units)
 {
     const grt_ctx* sc = scene_of(c);
     if (!c->opt_quad_parts || sc->n_faces || sc->has_pieces) return false;
-    return c->opt_quad_parts >= 2 || (n_units >= kTileResidentWaves / 2u && n_units <= 3u * kTileResidentWaves);
+    return c->opt_quad_parts >= 2 || n_units <= 3u * kTileResidentWaves;
 }
 // the four-way threshold such launches use: parts on the quad kernel cost a third of what part waves of the camera-ray kernel cost, so
 // more tiles are worth splitting the fewer tiles there are per resident wave — pct4 at two tiles per wave, half of it at one and below
@@ -1142,16 +1149,18 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
         // (every entry starts as padding: an entry the ordering kernels ever failed to write would make its wave exit instead of
         //  indexing costs, queues and pixels with whatever the allocation held — the likely cause of round 4's one unexplained abort,
         //  profiles/r05_experiments_log.md 1)
-        CHK(c, hipMemset(c->d_order, 0xFF, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u)));
+        // (on the FRAME'S stream, as everything below: a null-stream hipMemset is not ordered against a non-blocking stream and
+        //  may land after the kernels of this very frame have written the array)
+        CHK(c, hipMemsetAsync(c->d_order, 0xFF, sizeof(uint32_t) * ((size_t)n_units + parts_extra_cap(n_units) + 4u), s));
         if (!c->d_ord_scratch) { // counts and cursors of the several-workgroup ordering (grt_bvh.hip: k_ord_a); zero once, phase C keeps it so
             CHK(c, hipMalloc(&c->d_ord_scratch, order_scratch_bytes()));
-            CHK(c, hipMemset(c->d_ord_scratch, 0, order_scratch_bytes()));
+            CHK(c, hipMemsetAsync(c->d_ord_scratch, 0, order_scratch_bytes(), s));
         }
         CHK(c, hipMalloc(&c->d_cost_dil, sizeof(uint32_t) * n_units));
         CHK(c, hipMalloc(&c->d_qparts, sizeof(uint32_t) * kQuadListCap));
         if (!c->d_qpcount) {
             CHK(c, hipMalloc(&c->d_qpcount, 2 * sizeof(uint32_t)));
-            CHK(c, hipMemset(c->d_qpcount, 0, 2 * sizeof(uint32_t)));
+            CHK(c, hipMemsetAsync(c->d_qpcount, 0, 2 * sizeof(uint32_t), s));
         }
         c->cost_cap = n_units;
     }
@@ -1382,7 +1391,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         if (rco != GRT_OK) return rco;
         if (!c->d_ovf_next) { // [0] next free chunk, [1] running peak of the demand (k_frame_tail)
             CHK(c, hipMalloc(&c->d_ovf_next, 2 * sizeof(uint32_t)));
-            CHK(c, hipMemset(c->d_ovf_next, 0, 2 * sizeof(uint32_t)));
+            CHK(c, hipMemsetAsync(c->d_ovf_next, 0, 2 * sizeof(uint32_t), s));
             c->ovf_zeroed = true;
         }
     }

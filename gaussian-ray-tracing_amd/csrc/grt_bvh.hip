@@ -435,6 +435,74 @@ __global__ void k_refit_pass(float4* __restrict__ nodes, uint32_t* __restrict__ 
     level[i] = pass;
 }
 
+// ---- tree rotations: the quality pass behind the Karras build (reference: OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, src/GaussianTracer.cpp:360) ----
+// An LBVH takes its topology from the Morton order alone; where proxies of very different sizes overlap (a trained scene, the needle /
+// sheet scene C3a) a node often pairs a large box with a small one although a grandchild would make the tighter pair.  One bottom-up
+// sweep of ROTATIONS (Kensler 2008) repairs the worst of that: for node N = (S, R) with R = (RL, RR) internal, swapping the sibling S
+// with RL or RR changes nothing but R's own box; the swap that shrinks R's surface area most is applied (four candidates per node: either
+// child may play R).  N's box is the union of the same three boxes as before, so nothing above N changes; every node record holds its
+// two children's boxes, so a swap rewrites two records, N's and R's, and needs no parent pointers.  Nodes are taken in the order the
+// refit finished them (a pass per level, a kernel per pass: R was finished before N), after the bottom subtrees have been collapsed into
+// leaf ranges — a range stays a contiguous run of the sorted primitives, whatever happens above it.  Culling structure only: hits never
+// depend on it.
+__device__ __forceinline__ float box_area6(const float* b)
+{
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ __forceinline__ float union_area6(const float* a, const float* b)
+{
+    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ __forceinline__ void node_children(const float4* __restrict__ nodes, uint32_t i, float b0[6], float b1[6], uint32_t& c0, uint32_t& c1)
+{
+    const float4 q0 = nodes[(size_t)i * 4], q1 = nodes[(size_t)i * 4 + 1], q2 = nodes[(size_t)i * 4 + 2], q3 = nodes[(size_t)i * 4 + 3];
+    b0[0] = q0.x; b0[1] = q0.y; b0[2] = q0.z; b0[3] = q0.w; b0[4] = q1.x; b0[5] = q1.y;
+    b1[0] = q1.z; b1[1] = q1.w; b1[2] = q2.x; b1[3] = q2.y; b1[4] = q2.z; b1[5] = q2.w;
+    c0 = __float_as_uint(q3.x); c1 = __float_as_uint(q3.y);
+}
+__device__ __forceinline__ void node_store(float4* __restrict__ nodes, uint32_t i, const float b0[6], const float b1[6], uint32_t c0, uint32_t c1)
+{
+    nodes[(size_t)i * 4 + 0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+    nodes[(size_t)i * 4 + 1] = make_float4(b0[4], b0[5], b1[0], b1[1]);
+    nodes[(size_t)i * 4 + 2] = make_float4(b1[2], b1[3], b1[4], b1[5]);
+    nodes[(size_t)i * 4 + 3] = make_float4(__uint_as_float(c0), __uint_as_float(c1), 0.0f, 0.0f);
+}
+__global__ void k_rotate_pass(float4* __restrict__ nodes, const uint32_t* __restrict__ level, int m, uint32_t pass, uint32_t* __restrict__ n_done)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1 || level[i] != pass) return;
+    float bc[2][6];
+    uint32_t cc[2];
+    node_children(nodes, (uint32_t)i, bc[0], bc[1], cc[0], cc[1]);
+    float best = 0.0f; // largest reduction of R's area found
+    int bk = -1, bg = 0;
+    float g[2][2][6];
+    uint32_t gc[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { // child k plays R, child 1 - k the sibling S
+        if (cc[k] & kLeafBit) continue;
+        node_children(nodes, cc[k], g[k][0], g[k][1], gc[k][0], gc[k][1]);
+        const float a_old = box_area6(bc[k]);
+#pragma unroll
+        for (int t = 0; t < 2; t++) { // S <-> grandchild t: R' = (S, grandchild 1 - t)
+            const float gain = a_old - union_area6(bc[1 - k], g[k][1 - t]);
+            if (gain > best) { best = gain; bk = k; bg = t; }
+        }
+    }
+    if (bk < 0 || !(best > 1e-6f * box_area6(bc[bk]))) return;
+    const int k = bk, t = bg;
+    // R' = (S, G[1-t]) keeps R's index; N = (G[t], R') in R's place
+    float nb[6];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { nb[q] = fminf(bc[1 - k][q], g[k][1 - t][q]); nb[q + 3] = fmaxf(bc[1 - k][q + 3], g[k][1 - t][q + 3]); }
+    node_store(nodes, cc[k], bc[1 - k], g[k][1 - t], cc[1 - k], gc[k][1 - t]);
+    if (k == 0) node_store(nodes, (uint32_t)i, nb, g[k][t], cc[k], gc[k][t]);
+    else        node_store(nodes, (uint32_t)i, g[k][t], nb, gc[k][t], cc[k]);
+    if (n_done) atomicAdd(n_done, 1u);
+}
+
 // ---- launch order of the scheduling units: heaviest first, by cost CLASS ----
 // A class keeps the leading 3 bits of the cost (124 classes); inside a class the units stay in (approximately) screen
 // order, so neighbours that share BVH nodes are launched together and — through the XCD-aware rank map of the kernels —
@@ -1292,6 +1360,17 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     HIPCHK(hipMalloc(&out->wnodes, sizeof(float4) * 8 * (size_t)(m - 1) + 256));
     if (leaf_max > 1)
         hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
+    // ONE bottom-up sweep of rotations, for the Gaussian BVH of a scene with pieces (widen_area_only: needles and sheets — where large
+    // and small boxes overlap and the sweep pays: C3a 14.56 -> 13.77 ms; compact scenes: C3 / C2 flat, C5 -1 %, two of the three dense-core
+    // cameras +3 / +13 %: left alone).  One sweep only: a second one would need the levels re-derived (after a swap a node and its new child
+    // can carry the same stale level, and two threads of one pass then rewrite one record: seen as changed pixels).  GRT_BVH_ROTATIONS=0 / 1
+    // overrides the choice (tuning aid).
+    {
+        static const char* env = getenv("GRT_BVH_ROTATIONS");
+        const bool rotate = want_quad && (env ? atoi(env) != 0 : widen_area_only);
+        for (uint32_t pass = 2; rotate && pass <= out->height; pass++)
+            hipLaunchKernelGGL(k_rotate_pass, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_level, (int)m, pass, (uint32_t*)nullptr);
+    }
     hipLaunchKernelGGL(k_widen, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->wnodes);
     if (want_quad) {
         HIPCHK(hipMalloc(&out->qnodes, sizeof(float4) * 2 * kTileWide * (size_t)(m - 1) + 256));

@@ -206,8 +206,8 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_QUAD_PARTS = 33          /* 1 (default): the four-way parts of camera-ray frames without meshes or pieces run on the QUAD kernel
                                            (one 4x4 quadrant per wave, lanes = rays x slots: four survivors of a leaf step are slab-tested
                                            at once, one per slot, a ray's pending events are the pool of its four windows), launched beside
-                                           the camera-ray kernel — in launches that their parts bound (2048 .. 12 288 tiles: a rank's share
-                                           of a frame), with a four-way threshold scaled down to half for launches of one tile per resident
+                                           the camera-ray kernel — in launches that their parts bound (up to 12 288 tiles: a small frame, a
+                                           rank's share of a frame), with a four-way threshold scaled down to half for launches of one tile per resident
                                            wave and fewer; 2: whatever the size (testing); > 2: and at most that many parts (testing); 0: part
                                            waves of the camera-ray kernel with 16 of 64 lanes in use (round 4).  Same pixels either way */ };
 
