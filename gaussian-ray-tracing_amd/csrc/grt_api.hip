@@ -518,6 +518,7 @@ int grt_create_view(grt_ctx* parent, grt_ctx** out)
     if (rc != GRT_OK) return rc;
     v->parent = parent;
     parent->n_views++;
+    parent->views.push_back(v);
     *out = v;
     return GRT_OK;
 }
@@ -581,6 +582,7 @@ void grt_destroy(grt_ctx* c)
     (void)hipDeviceSynchronize(); // renders of this slot (and, for a scene, of its views) may be in flight on any stream
     if (c->parent) {
         grt_ctx* p = c->parent;
+        p->views.erase(std::remove(p->views.begin(), p->views.end(), c), p->views.end());
         destroy_now(c);
         if (--p->n_views == 0 && p->zombie) destroy_now(p);
         return;
@@ -1070,11 +1072,23 @@ static uint32_t parts_extra_cap(uint32_t n_units)
 // profiles/r05_experiments_log.md 4: a 256^2 frame, 1024 tiles, 0.46 -> 0.27 ms; a rank's share of a 1080p frame, 4050 / 8100 tiles,
 // 0.77 -> 0.55 / 0.75 -> 0.61 ms; a 720p frame of 14 400 tiles is bound by its total work and loses 5 % to the second kernel).
 // GRT_OPT_QUAD_PARTS = 2 forces it on whatever the size (tests).
+// is a frame of another slot of this scene still running?  (its frame-end event, recorded on its stream behind its last kernels)
+static bool sibling_frames_in_flight(const grt_ctx* c)
+{
+    const grt_ctx* sc = scene_of(c);
+    if (sc->n_views == 0) return false;
+    auto busy = [&](const grt_ctx* s) { return s != c && s->have_timing && s->ev1 && hipEventQuery(s->ev1) == hipErrorNotReady; };
+    if (busy(sc)) return true;
+    for (const grt_ctx* v : sc->views) if (busy(v)) return true;
+    return false;
+}
 static bool quad_parts_ok(const grt_ctx* c, uint32_t n_units)
 {
     const grt_ctx* sc = scene_of(c);
     if (!c->opt_quad_parts || sc->n_faces || sc->has_pieces) return false;
-    return c->opt_quad_parts >= 2 || n_units <= 3u * kTileResidentWaves;
+    // (while frames of the scene's OTHER slots are in flight the machine is shared, the frames are bound by their total work and the quad
+    //  kernel — a latency tool — only takes capacity: a rank of 8 with eight frames in flight 0.26 -> 0.33 ms per frame with it)
+    return c->opt_quad_parts >= 2 || (n_units <= 3u * kTileResidentWaves && !sibling_frames_in_flight(c));
 }
 // the four-way threshold such launches use: parts on the quad kernel cost a third of what part waves of the camera-ray kernel cost, so
 // more tiles are worth splitting the fewer tiles there are per resident wave — pct4 at two tiles per wave, half of it at one and below

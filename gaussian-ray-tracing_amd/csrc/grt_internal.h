@@ -237,6 +237,7 @@ int order_units_by_cost(const uint32_t* d_cost, uint32_t* d_order, uint32_t n, u
 struct grt_ctx {
     grt_ctx* parent = nullptr; // view: the context whose scene this one renders
     int n_views = 0;           // live views of this context
+    std::vector<grt_ctx*> views; // ... and which (a scene's frame slots look at each other's frame-end events: are frames in flight?)
     bool zombie = false;       // destroyed while views were alive: freed with the last of them
     uint64_t seen_epoch = 0;   // scene_epoch of the scene at this slot's last launch
     int device = 0;

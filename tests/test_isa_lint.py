@@ -266,6 +266,16 @@ def test_isa_budget_of_the_render_kernels():
     # (SGPR-spill traffic inside loops predicts the frame: 146 / 171 / 210 v_readlane + v_writelane in loops = -2.7 % / 0 / +3.6 % on C3,
     #  profiles/r04_experiments_log.md 10)
     assert c3["lane_moves"] <= 165 and c3["lane_moves_in_loops"] <= 145 and c3["spilled_sgprs"] <= 8 and c3["instructions"] <= 5200, c3
+    # the mesh frame's stages (C4): guarded where they stand (VERDICT r04 asked for <= 200 / <= 20 / <= 300; not reached this round —
+    # what is asserted is that they do not get WORSE unseen, the uninstrumented instantiations that frames run)
+    for name, k in tile.items():
+        if not name.startswith("grt::k_render_tile<false"):
+            continue
+        mode = int(re.search(r"k_render_tile<\w+, \w+, \w+, (\d)", name).group(1))
+        if mode == 1:
+            assert k["lane_moves_in_loops"] <= 260 and k["spill_instructions_in_loops"] <= 60, (name, k)
+        if mode == 2:
+            assert k["lane_moves_in_loops"] <= 400 and k["spill_instructions_in_loops"] <= 24, (name, k)
     c5 = b["grt::k_render_tile<false, false, false, 0, true>"]  # the same with pieces (needle / sheet scenes)
     assert c5["spill_instructions_in_loops"] <= 2 and c5["spill_instructions"] <= 16, c5  # (two in its piece-ownership block)
 
