@@ -478,7 +478,8 @@ def main():
                        "bvh_height": info["height"], "n_proxies": info["n_proxies"], "n_bvh_primitives": info["n_primitives"], "bvh_build_ms": round(info["build_ms"], 2),
                        "setup_s": round(setup_s, 2), "kernel_variant": args.kernel, "options": args.opt or None,
                        "scheduling": "8x8 tiles launched heaviest-first from the previous frame's per-tile cost "
-                                     "(steady state of an interactive viewer); kernel_ms_cold / frame_ms_cold (wall, synchronised): a frame with no "
+                                     "(steady state of an interactive viewer); launches of <= 12288 tiles with no other frame slot in flight run "
+                                     "their heaviest tiles as 4x4 quadrants on the quad kernel (lanes = rays x slots) beside the camera-ray kernel; kernel_ms_cold / frame_ms_cold (wall, synchronised): a frame with no "
                                      "previous costs, tiles ordered by projected particle counts; kernel_ms_cold_screen_order: the same in screen order; "
                                      "kernel_ms_orbit: the eye orbits the look-at point by 1.5 degrees per frame "
                                      "(per-eye records rebuilt, last frame's costs order a different frame)",
