@@ -1601,9 +1601,7 @@ int launch_render_tile(const RenderArgs& a, bool count, bool mesh, int mode, hip
         if (rq != GRT_OK) return rq;
         main_stream = aux->aux;
     }
-    static const char* padenv = getenv("GRT_TILE_LDS_PAD"); // EXPERIMENT: extra dynamic LDS per wave (bytes) for launches of <= 4096 waves: spreads them over the CUs
-    const size_t pad = (padenv && mode == 0 && grid <= 4096u) ? (size_t)atoi(padenv) : 0;
-    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), pad, main_stream, b);
+    hipLaunchKernelGGL(pick_tile(count, sh, mesh || mode != 0, mode, a.has_pieces != 0u), dim3(grid), dim3(kWG), 0, main_stream, b);
     if (quad) {
         hipError_t eq = hipEventRecord(aux->join, aux->aux);
         if (eq == hipSuccess) eq = hipStreamWaitEvent(stream, aux->join, 0);
