@@ -626,7 +626,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
-    else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; }
+    else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; }
     else if (option == GRT_OPT_OVF_ENTRIES) {
         if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
         c->opt_ovf_entries = value;
@@ -1123,7 +1123,7 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         const bool quad = quad_parts_ok(c, n_units) && c->d_qparts;
         int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
                                          quad ? quad_pct4(c, n_units) : (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, c->d_ord_scratch,
-                                         (uint32_t)c->opt_order_multi_min, s, &c->err);
+                                         (uint32_t)c->opt_order_multi_min, true, s, &c->err);
         if (rcp == GRT_OK) {
             c->order_launch = n_units + cap;
             c->qparts_valid = false;
@@ -1239,7 +1239,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             const uint32_t cap = parts_extra_cap(n_units);
             rc = order_units_with_parts(src, c->d_cost_dil, c->d_order, n_units, cap, 0u, (uint32_t)c->opt_cold_parts_pct,
                                         (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, nullptr, c->d_ord_scratch,
-                                        (uint32_t)c->opt_order_multi_min, s, &c->err);
+                                        (uint32_t)c->opt_order_multi_min, false /* (particle counts, not cost words) */, s, &c->err);
             if (rc == GRT_OK) {
                 c->order_launch = n_units + cap; a.n_launch = c->order_launch;
                 c->qparts_valid = false;
@@ -1268,43 +1268,66 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
     return GRT_OK;
 }
 
-// The tile kernel's pool of window-overflow bags: a chunk (kTileOvfChunkBytes = 96 KiB) per tile that overflows.  A tile
-// that finds the pool empty falls back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the
-// default 1 M scene and cost that frame 12 %, and on the needle scene C3a a pool of 3/8 of the tiles made the first
-// frames 2.3 x slower).  Round 2 held a chunk for EVERY tile of the launch for good (3.1 GB at 1080p, 12.4 GB at 4K, per
-// frame slot).  Now the pool follows the DEMAND: the chunk counter of every frame is read back behind it (pinned word, no
-// sync); the first frame of a launch geometry still gets a chunk per tile (or what a sibling frame slot of the same
-// scene has learnt), and as soon as a demand is known the pool is re-sized to 1.25 x the largest demand seen + 64.  An
-// allocation that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation
-// buffer.
+// The tile kernel's pool of window-overflow bags, in chunks of kTileOvfChunkBytes = 32 KiB (32 entries x 64 lanes): a tile that
+// overflows takes one, and up to two more as its fullest bag grows (grt_render_tile.hip).  A tile that finds the pool empty falls
+// back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the default 1 M scene and cost that frame 12 %, and
+// on the needle scene C3a a pool of 3/8 of the tiles made the first frames 2.3 x slower).  Round 2 held a full bag for EVERY tile
+// of the launch for good (3.1 GB at 1080p, 12.4 GB at 4K, per frame slot); rounds 3-4 sized the pool from the largest demand
+// ever seen, in whole 96-entry bags (1.3 GB at 1080p).  Now the pool follows the DEMAND both ways: every frame's chunk counter is
+// read back behind it (pinned word, no sync; the device keeps the peak between two reads), the last eight readings are kept, and
+// the pool is 1.25 x their MEDIAN + 64 — re-made when the median comes within 10 % of it, or when it is more than 1.2 x what
+// that rule asks for (a re-size waits for the device: the band keeps a drifting demand from paying that every frame).  The first frame of a
+// launch geometry still gets three chunks per tile (or what a sibling frame slot of the same scene has learnt).  An allocation
+// that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation buffer.
+static uint32_t overflow_demand_median(const grt_ctx* c)
+{
+    if (!c->ovf_hist_n) return 0u;
+    uint32_t v[8];
+    const uint32_t n = std::min(c->ovf_hist_n, 8u);
+    for (uint32_t i = 0; i < n; i++) v[i] = c->ovf_hist[i];
+    std::sort(v, v + n);
+    return v[n / 2u]; // (the upper median of an even count)
+}
+
 static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
 {
     grt_ctx* sc = scene_of(c);
+    if (c->ovf_units != n_tiles) { c->ovf_hist_n = 0; c->ovf_demand = 0; c->ovf_short = false; c->ovf_units = n_tiles; c->ovf_stale = c->ovf_pending; } // another launch geometry: start over
     if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
-        c->ovf_demand = std::max(c->ovf_demand, std::max(*c->h_ovf_used, 1u));
+        if (!c->ovf_stale) { // (a reading asked for under the geometry before says nothing about this one)
+            c->ovf_hist[c->ovf_hist_n % 8u] = std::max(*c->h_ovf_used, 1u);
+            c->ovf_hist_n++;
+            c->ovf_demand = overflow_demand_median(c);
+            sc->ovf_hint_units = c->ovf_units;
+            sc->ovf_hint = c->ovf_demand;
+        }
+        c->ovf_stale = false;
         c->ovf_pending = false;
-        if (sc->ovf_hint_units != c->ovf_units || sc->ovf_hint < c->ovf_demand) { sc->ovf_hint_units = c->ovf_units; sc->ovf_hint = c->ovf_demand; }
     }
-    if (c->ovf_units != n_tiles) { c->ovf_demand = 0; c->ovf_units = n_tiles; } // another launch geometry: start over
     const uint32_t cap = (uint32_t)((16ull << 30) / kTileOvfChunkBytes);
-    const uint32_t most = std::min(cap, std::max(n_tiles, 1u));
+    const uint32_t most = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)n_tiles * kTileOvfChunksPerTile, 1u));
     uint32_t want;
-    bool known = false;
+    bool resize;
     if (c->opt_ovf_chunks != 0) {
         want = c->opt_ovf_chunks > 0 ? (uint32_t)c->opt_ovf_chunks : 0u;
-        known = true;
+        resize = c->ovf_chunks != want;
     } else {
         const uint32_t d = c->ovf_demand ? c->ovf_demand : ((sc->ovf_hint_units == n_tiles) ? sc->ovf_hint : 0u);
-        known = d != 0u;
-        want = known ? std::min(most, d + d / 4u + 64u) : most;
+        if (d == 0u) { // nothing known yet
+            want = most;
+            resize = c->ovf_chunks < want && !c->ovf_short;
+        } else {
+            want = std::min(most, d + d / 4u + 64u);
+            resize = (c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short) || c->ovf_chunks > want + want / 5u;
+        }
     }
-    const bool shrink = known && (c->opt_ovf_chunks != 0 ? c->ovf_chunks != want : c->ovf_chunks > 2u * want + 256u);
-    if (c->ovf_chunks < want || shrink) {
+    if (resize) {
         if (c->d_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); } // a frame in flight may still use it
         c->d_ovf = nullptr;
         c->ovf_chunks = 0;
         for (uint32_t n = want; n >= 1u; n /= 2u) {
             if (hipMalloc(&c->d_ovf, (size_t)n * kTileOvfChunkBytes) == hipSuccess) { c->ovf_chunks = n; break; }
+            c->ovf_short = true; // (the memory is not there: growing is not tried again for this launch geometry)
             (void)hipGetLastError(); // out of memory is not an error of the frame: a smaller pool, or none
             c->d_ovf = nullptr;
             if (c->opt_ovf_chunks > 0) break;

@@ -573,6 +573,16 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* cost, uint3
     if (zero) for (uint32_t i = tid; i < n; i += 1024u) zero[i] = 0u;
 }
 
+// The chunks of the overflow pool a whole tile takes in the frame this order is made for, from the two lowest bits of its cost word
+// (grt_render_tile.hip kBagKeep1 / kBagKeep2: how full the fullest bag of any of its rays got): 1, 2, or 0 = a full bag (three) —
+// also for a tile without a cost, and when the costs are not the tile kernel's words at all (the cold frame's particle counts)
+__device__ __forceinline__ uint32_t bag_class(uint32_t enabled, uint32_t cost_word)
+{
+    if (!enabled || cost_word == 0u) return 0u;
+    const uint32_t d = cost_word & 3u;
+    return d == 0u ? 1u : (d == 1u ? 2u : 0u);
+}
+
 // The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes).  A frame takes at least
 // max(L, W / R): L the longest tile (one wave walking its frontier and compositing sweep after sweep: ~0.9 ms on the 1 M scene, half
 // the frame of one GPU and ALL of the frame of a rank that owns an eighth of the tiles), W the launch's total work, R the resident
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* cost, uint3
 // entries beyond one per tile: they go to the heaviest cost classes first.
 __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* cost, const uint32_t* raw, uint32_t n,
                                                            uint32_t* __restrict__ order, uint32_t extra_cap, uint32_t pct2, uint32_t pct4,
-                                                           uint32_t pct_load, uint32_t resident_waves, uint32_t* zero) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
+                                                           uint32_t pct_load, uint32_t resident_waves, uint32_t* zero, uint32_t bag_classes) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
 {
     __shared__ uint32_t hist[128], h2[128], h4[128], cursor[128];
     __shared__ uint8_t ok4[128], ok2[128]; // the launch has room for this cost class's four-way / two-way parts
@@ -712,7 +722,9 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* cost,
                 const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
                 const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
                 const uint32_t pos = atomicAdd(&cursor[b], parts);
-                for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+                // (a whole tile's part field carries its bags' size class: the chunks of the pool it takes, 0 = a full bag)
+                if (code == 0u) order[pos] = i | (bag_class(bag_classes, rv[k]) << 28);
+                else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
             }
             __syncthreads();
         }
@@ -874,7 +886,7 @@ __global__ __launch_bounds__(1024) void k_ord_c(uint32_t n, uint32_t groups, uin
 }
 __global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint32_t* raw, uint32_t n, uint32_t per,
                                                 uint32_t extra_cap, const uint32_t* __restrict__ S, uint32_t* __restrict__ order,
-                                                uint32_t* zero) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
+                                                uint32_t* zero, uint32_t bag_classes) // (`zero` is `raw`, and `cost` too when the map is not dilated: none of the three is restrict)
 {
     __shared__ uint32_t cursor[128];
     __shared__ uint8_t ok4[128], ok2[128];
@@ -885,12 +897,14 @@ __global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint
     for (uint32_t base = lo; base < hi; base += 1024u) { // (1024 units at a time, a barrier between them: the tiles of a class stay in screen order)
         const uint32_t i = base + tid;
         if (i < hi) {
-            const uint32_t r = cost_eff(raw[i]), b = 127u - cost_class(cost_eff(cost[i]));
+            const uint32_t rw = raw[i];
+            const uint32_t r = cost_eff(rw), b = 127u - cost_class(cost_eff(cost[i]));
             const bool two_way = t2 != 0xFFFFFFFFu;
             const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
             const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
             const uint32_t pos = atomicAdd(&cursor[b], parts);
-            for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
+            if (code == 0u) order[pos] = i | (bag_class(bag_classes, rw) << 28); // (the bags' size class: k_cost_order_parts)
+            else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
         }
         __syncthreads();
     }
@@ -948,9 +962,10 @@ int quad_part_list(uint32_t* d_order, uint32_t n_entries, uint32_t* d_list, uint
 
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
-                           uint32_t multi_min, hipStream_t stream, std::string* err)
+                           uint32_t multi_min, bool bag_classes, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
+    const uint32_t cls = bag_classes ? 1u : 0u; // (d_cost_raw holds cost words of the tile kernel: their lowest bit is the bags' size class)
     if (d_scratch && n >= multi_min) { // several workgroups, four phases (see k_ord_a)
         uint32_t per = 2048u; // units per workgroup: two runs of 1024
         if ((n + per - 1u) / per > kOrdMaxGroups) per = (((n + kOrdMaxGroups - 1u) / kOrdMaxGroups) + 1023u) & ~1023u;
@@ -958,10 +973,10 @@ int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_
         hipLaunchKernelGGL(k_ord_a, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, d_scratch);
         hipLaunchKernelGGL(k_ord_b, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, pct2, pct4, pct_load, resident_waves, d_scratch);
         hipLaunchKernelGGL(k_ord_c, dim3(1), dim3(1024), 0, stream, n, groups, extra_cap, pct2, pct4, pct_load, resident_waves, d_scratch, d_order);
-        hipLaunchKernelGGL(k_ord_d, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, extra_cap, (const uint32_t*)d_scratch, d_order, d_zero);
+        hipLaunchKernelGGL(k_ord_d, dim3(groups), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, per, extra_cap, (const uint32_t*)d_scratch, d_order, d_zero, cls);
     } else
     hipLaunchKernelGGL(k_cost_order_parts, dim3(1), dim3(1024), 0, stream, d_cost_order, d_cost_raw, n, d_order, extra_cap, pct2, pct4, pct_load,
-                       resident_waves, d_zero);
+                       resident_waves, d_zero, cls);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         if (err) *err = std::string("order_units_with_parts: ") + hipGetErrorString(e);

@@ -192,7 +192,9 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
 constexpr int kWfCounters = 3 * kMaxBundleRounds + 3;
 constexpr uint32_t kTileOvfEntries = 96u; // per-lane capacity of a window-overflow bag
-constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfEntries * 64 * 16;
+constexpr uint32_t kTileOvfSub = 32u;     // ... handed out this many entries at a time: a chunk of the pool = 32 entries x 64 lanes
+constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfSub * 64 * 16; // 32 KiB; a tile holds up to kTileOvfEntries / kTileOvfSub of them
+constexpr uint32_t kTileOvfChunksPerTile = kTileOvfEntries / kTileOvfSub;
 // GRT_OPT_KERNEL values: 0 auto (tile kernel where it applies, else streaming), 1 per-lane, 2 round-based wave,
 // 3 streaming, 4 big-window streaming (testing), 5 tile
 constexpr int GRT_KERNEL_MAX = 5;
@@ -219,7 +221,7 @@ int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uin
 // (d_scratch: order_scratch_bytes() of device memory, zeroed once; launches of multi_min units and more are ordered by several workgroups)
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
-                           uint32_t multi_min, hipStream_t stream, std::string* err);
+                           uint32_t multi_min, bool bag_classes, hipStream_t stream, std::string* err);
 uint32_t order_scratch_bytes();
 // the first kQuadListCap four-way part entries of a launch order (n_entries of them incl. padding), in order, listed in d_list and re-coded
 // 2 -> 3 in the order itself; d_count[0] = how many
@@ -263,7 +265,11 @@ struct grt_ctx {
     uint32_t* h_ovf_used = nullptr; // pinned: chunks the last finished frame asked for (read back behind every frame)
     hipEvent_t ev_ovf = nullptr;
     bool ovf_pending = false;
-    uint32_t ovf_demand = 0;      // largest demand seen for the current pool geometry
+    uint32_t ovf_demand = 0;      // the demand the pool follows: median of the last eight readings for the current launch geometry
+    uint32_t ovf_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // ... those readings (a ring: ovf_hist_n counts all of them)
+    uint32_t ovf_hist_n = 0;
+    bool ovf_stale = false;       // the reading on its way was asked for under another launch geometry
+    bool ovf_short = false;       // an allocation of the size wanted failed
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT

@@ -56,8 +56,18 @@ constexpr uint32_t kStack = kTileStack; // depth-first overflow stack (only when
                                   // admits only trees it can hold: tile_stack_fits).  LDS per wave must stay <= 10 KB:
                                   // 10304 B gave 15 waves per CU instead of 16 and cost 4 %
 constexpr uint32_t kKeep = 40u; // frontier entries kept in registers by a rebalance (the nearest ones)
-constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a lane's column of an overflow chunk holds; the
-                                           // capacity in use is a.ovf_entries (<= kOvf; smaller only in tests)
+constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a lane's overflow bag holds at most; the capacity in use is
+                                           // a.ovf_entries (<= kOvf; smaller only in tests)
+constexpr uint32_t kSub = kTileOvfSub;     // The pool is handed out in CHUNKS of kSub entries x 64 lanes (32 KiB).  A tile takes three in a
+                                           // row (a full bag per ray) — or two, or ONE, when its bags stayed shallow in the frame before:
+                                           // the cost word's two lowest bits say how full the fullest bag of any of its rays got (0: at most
+                                           // kBagKeep1 entries, 1: at most kBagKeep2, 3: more), the launch order hands the size class
+                                           // back in the part field of a whole tile's entry (grt_bvh.hip).  Of the tiles of the 1 M scene
+                                           // that overflow at all, half never hold more than 16 entries in any bag, 79 % never more than
+                                           // 32, 95 % never more than 48.  A tile that outgrows its chunks prunes and drops as any full bag
+                                           // does (another pass at worst) and takes more in the next frame.
+constexpr uint32_t kBagKeep1 = 20u, kBagKeep2 = 48u; // (a class's bags are pruned 8 entries short of full: at 24 and 56)
+static_assert(kOvf == 3u * kSub && kBagKeep1 < kSub && kBagKeep2 < 2u * kSub, "a full bag is three chunks");
 constexpr int kBisect = 18;          // most bisection steps of a nearest-k selection (4 / 6 at least)
 constexpr uint32_t kPruneRoom = 32u; // a window bag with less room than this is pruned between steps
 constexpr int kWavesPerSimd = 4;     // waves per SIMD the camera-ray and bundle kernels are compiled for (128 VGPRs)
@@ -66,7 +76,8 @@ constexpr int kWavesQuad = 3;        // ... the quad kernel (MODE 3: per-lane re
 // launch order and the part-wave policy live on that word, and steps alone are a poor proxy of a tile's TIME (a leaf step that carries
 // sixteen ranges through their exact tests and a node step count the same).  Same-box kernel ms with it: C1 0.513 -> 0.472, C2 0.955 ->
 // 0.89, a rank of eight 0.757 -> 0.737; other weightings and the wave's own clock: profiles/r04_experiments_log.md 19.
-constexpr uint32_t kCostFetch = 2u, kCostTest = 12u;
+constexpr uint32_t kCostFetch = 4u, kCostTest = 24u; // (in sixteenths of a step)
+static_assert(kCostFetch % 4u == 0u && kCostTest % 4u == 0u, "the two lowest bits of a camera-ray tile's `work` are its bags' depth class");
 
 // The only compile-time variants of this file: GRT_TILE_KS = 8 with GRT_TILE_SINGLE_TU (grt_render_tile_single.hip: the one-ray-per-wave
 // mode as a translation unit of its own, 3 waves per SIMD), GRT_TILE_DIAG (wave-level trip counts in the counters), GRT_TILE_CHECK
@@ -591,11 +602,14 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
 #ifdef GRT_TILE_CHECK
         uint32_t dbg_n = 0, dbg_m = 0;
 #endif
-        uint32_t chunk = kNoRoot; // this tile's chunk of the overflow pool (taken at the first window overflow)
+        uint32_t chunk = kNoRoot; // this tile's first chunk of the overflow pool (taken at the first window overflow)
         // (QUAD: a ray's four bags TOGETHER hold what one bag of the camera-ray kernel holds.  The capacity is a cut-off, not just room:
         //  a ray whose bag is full stops wanting what lies beyond, the tile's reach shrinks with it and the frontier stays clear of far
         //  entries — with four full-size bags a quadrant of a cluster core went on for 242 steps where the part wave took 164)
-        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : a.ovf_entries, prune_room = QUAD ? kPruneRoom / 4u : kPruneRoom;
+        // (a whole tile whose bags stayed shallow in the frame before — part field 1 or 2 of its order entry — lives in one or two chunks)
+        const uint32_t cls_ = (MODE == 0 && a.order && (ue >> 30) == 0u) ? ((ue >> 28) & 3u) : 0u; // chunks the tile lives in (0: a full bag)
+        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : (cls_ ? min(a.ovf_entries, cls_ * kSub) : a.ovf_entries);
+        const uint32_t prune_room = QUAD ? kPruneRoom / 4u : (cls_ ? kSub / 4u : kPruneRoom);
         const uint32_t ready_min = SINGLE ? 1u : a.tile_ready_min; // lanes with a final event before a compositing sweep starts
         // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
         const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;
@@ -775,7 +789,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
                     const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + prune_room >= bag_cap);
                     if (wave_any(pr_)) { // wave-uniform, rare
-                        bag_prune(a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane, pr_, nb, bagmin, lost);
+                        work |= 3u; // (deep bags: below)
+                        bag_prune(a.ovf_pool + (size_t)chunk * (kSub * 64u) + lane, pr_, nb, bagmin, lost);
                         if (QUAD) lost = quad_umin64(lost);
                         lim_dirty = true;
                     }
@@ -863,9 +878,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
                             uint32_t nmax = rf ? nb : 0u;
                             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, off));
                             nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+                            work |= (nmax > kBagKeep2) ? 3u : ((nmax > kBagKeep1) ? 1u : 0u);
                             uint32_t w_ = 0;
                             uint64_t newmin = kKeyInvalid;
-                            float4* bp = a.ovf_pool + (size_t)chunk * (kOvf * 64u) + lane;
+                            float4* bp = a.ovf_pool + (size_t)chunk * (kSub * 64u) + lane;
                             for (uint32_t i = 0; i < nmax; i++) {
                                 const bool v_ = rf && (i < nb);
                                 float4 e_ = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1267,16 +1283,18 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
                             const uint32_t cell = full ? (uint32_t)(KLAST & kCellMask) : (uint32_t)__builtin_ctz(~pmask);
                             if (wave_any(drop)) {
                                 if (!SINGLE && chunk == kNoRoot) {
+                                    // (as many chunks as the bags may grow to: QUAD — a ray's four bags hold a quarter each — one always)
+                                    const uint32_t nch = (bag_cap + kSub - 1u) / kSub;
                                     uint32_t ch = 0;
-                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, 1u);
+                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, nch);
                                     ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
-                                    chunk = (ch < a.ovf_chunks) ? ch : (kNoRoot - 1u);
+                                    chunk = (ch + nch <= a.ovf_chunks) ? ch : (kNoRoot - 1u);
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
                                 const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < bag_cap) && (dk < lost);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
-                                    a.ovf_pool[((size_t)chunk * kOvf + nb) * 64u + lane] =
+                                    a.ovf_pool[((size_t)chunk * kSub + nb) * 64u + lane] =
                                         make_float4(__uint_as_float((uint32_t)dk), __uint_as_float((uint32_t)(dk >> 32)), d_o, d_a);
                                     nb++;
                                     bagmin = (dk < bagmin) ? dk : bagmin;
@@ -1351,6 +1369,10 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
             const bool progressed = last_key != pass_lo;
             stalls = parked ? stalls : (progressed ? 0u : stalls + 1u);
             const bool again = alive && (lost != kKeyInvalid);
+            // HOW DEEP the bags got (0: no ray's bag held more than kBagKeep1 entries, 1: none more than kBagKeep2, 3: more — the tile wants
+            // a full bag per ray next frame too) is noted in the two lowest bits of `work`, which the camera-ray kernel only ever raises by
+            // multiples of four: at a prune, at a refill scan, and here — what the bags hold at the end of a pass was never scanned
+            if (MODE == 0 && bags) work |= wave_any(nb > kBagKeep2) ? 3u : (wave_any(nb > kBagKeep1) ? 1u : 0u);
             if (COUNT && again && stalls >= 2u) c.stall_exits++;
             if (wave_any(again && stalls >= 2u)) { // (never seen)
                 if (MODE == 1) { aborted = true; break; }
@@ -1363,10 +1385,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         // the cost word: steps + the weighted particle work (kCostFetch, kCostTest).  The watchdog's reading of it, "steps > max_iters"
         // (k_check_costs), stays exact: the word is kept at or below max_iters unless the watchdog fired.
         if (!BUNDLE && a.cost && lane == 0) {
-            uint32_t cw = min((iters & kCostStepsMask) + (work >> 3), kCostStepsMask);
+            uint32_t cw = min((iters & kCostStepsMask) + (work >> 4), kCostStepsMask);
             // (max_iters <= kCostStepsMask - 1: grt_set_option; a stack-guard give-up has its own bit and is not a step watchdog)
             const bool over = watchdog && !(iters & kCostStackBit);
             cw = over ? max(cw, a.max_iters + 1u) : min(cw, a.max_iters);
+            // (two lowest bits: how deep the bags got)
+            if ((MODE == 0 || QUAD) && !over) { // (the part of a split tile: deep whatever its own bags did — the tile's word is the maximum of its parts')
+                cw = (cw & ~3u) | ((QUAD || (ue >> 30) != 0u) ? 3u : (work & 3u));
+                cw = (cw > a.max_iters && cw >= 4u) ? cw - 4u : cw; // (still at or below max_iters, the bits kept)
+            }
             atomicMax(&a.cost[ue & kOrderUnitMask], (iters & (kCostStackBit | kCostStallBit)) | cw | (min(ue >> 30, 2u) << kCostPartShift));
         }
     }

@@ -52,8 +52,12 @@ ARCH = os.environ.get("GRT_ARCH", "gfx950")
 # (`scratch_store_dword* ... ; N-byte Folded Spill`: the value of the lanes that skipped the branch must reach the slot too)
 # — at a rule-(A) label also rematerialised constants (`v_mov_b32 vN, const`: nothing there can be a then-branch's phi copy) —
 # and nothing that stays between a moved store and the restore waits on the vector-memory counter or names a moved register
-# (s_waitcnt vmcnt / v_readlane / v_writelane: their order against the store would change).  Anything else — a reload, a
-# rematerialised constant (a then-branch's phi copy looks the same), a dependence — FAILS the build with the snippet.
+# (s_waitcnt vmcnt / v_readlane / v_writelane: their order against the store would change).  One exception, because it changes
+# no order at all: when EVERYTHING from the first moved store to the restore is a moved instruction, an s_waitcnt or an s_nop
+# (the allocator interleaves the stores with the waits for the loads whose results it spills), that whole tail goes behind the
+# restore as it stands — which is the same as hoisting the restore (a scalar instruction that reads an SGPR pair none of them
+# writes) in front of it.  Anything else — a reload, a rematerialised constant (a then-branch's phi copy looks the same), a
+# dependence — FAILS the build with the snippet.
 EXEC_WRITE = re.compile(r"^(s_\w+\s+exec\b|s_\w+_saveexec_b64\b|v_cmpx_)")
 WIDEN = re.compile(r"^(s_or_b64 exec, exec, s\[\d+:\d+\]|s_mov_b64 exec, s\[\d+:\d+\]|s_or_saveexec_b64 s\[\d+:\d+\], s\[\d+:\d+\])")
 EXEC_FREE = re.compile(r"^(s_|v_readlane_b32|v_writelane_b32|;|\.)")
@@ -153,8 +157,9 @@ class Asm:
                 return f"not a VGPR spill store: {u}"
             moved |= vgprs_of(u)
         stores = [k for k in off if SPILL_STORE.match(L[k].strip())]
+        tail = self.tail_with_waits(i, off)
         for k in range(off[0] + 1, i):  # what stays between the first moved instruction and the restore
-            if k in off:
+            if k in off or k in tail:
                 continue
             u = L[k].strip()
             if not u or u.startswith(";") or u.startswith("."):
@@ -164,6 +169,26 @@ class Asm:
             if vgprs_of(u) & moved:
                 return f"an instruction that stays between a moved store and the restore names a moved register: {u}"
         return None
+
+    def tail_with_waits(self, i, off):
+        """The s_waitcnt / s_nop lines that move WITH the offenders: all of them behind the first moved store, when nothing else
+        stands between that store and the restore (the tail then moves as one piece, its order unchanged); else none."""
+        L = self.L
+        stores = [k for k in off if SPILL_STORE.match(L[k].strip())]
+        if not stores:
+            return []
+        extra = []
+        for k in range(stores[0] + 1, i):
+            if k in off:
+                continue
+            u = L[k].strip()
+            if not u or u.startswith(";") or u.startswith("."):
+                continue
+            if re.match(r"^(s_waitcnt|s_nop)\b", u):
+                extra.append(k)
+            else:
+                return []
+        return extra
 
     def snippet(self, i):
         return "\n".join("    " + self.L[k] for k in range(max(self.block_top(i), i - 24), i + 1))
@@ -186,6 +211,7 @@ def repair(text):
                 if why:
                     raise ExecPrologueError(f"EXEC-dependent instructions in front of a join block's EXEC restore (line {i + 1}) that the "
                                             f"build will not move on its own — {why}\n{A.snippet(i)}")
+                off = sorted(set(off) | set(A.tail_with_waits(i, off)))
                 ins = [L[k] for k in off]
                 for k in reversed(off):
                     del L[k]

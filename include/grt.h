@@ -127,8 +127,8 @@ typedef struct {
     uint64_t scene_bytes;         /* device memory of the scene this context renders (shared by a context and its views) */
     uint64_t slot_bytes;          /* device memory of this frame slot: eye records, overflow pool, feedback, wavefront queues */
     uint64_t overflow_pool_bytes; /* of which: the tile kernel's pool of window-overflow bags */
-    uint32_t overflow_chunks;     /* chunks (96 KiB) in that pool */
-    uint32_t overflow_demand;     /* most chunks a finished frame of the current launch geometry asked for */
+    uint32_t overflow_chunks;     /* chunks (32 KiB: 32 entries x 64 rays; a tile takes up to three) in that pool */
+    uint32_t overflow_demand;     /* the demand the pool follows: median of what the last eight frames read back asked for */
 } grt_memory_info;
 
 enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_counters */,
@@ -178,7 +178,7 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                          geometric-mean proxy diagonal (default 512 = 8 x; 0 = relative bands only).  Scheduling only */,
        /* testing knobs (frames never change; speed and the failure signal do) */
        GRT_OPT_OVF_CHUNKS = 21        /* tile kernel's pool of window-overflow bags: 0 (default) = sized from the demand of the
-                                         frames before; n > 0: exactly n chunks; < 0: no pool (every overflow costs another pass) */,
+                                         frames before (1.25 x the median of eight); n > 0: exactly n chunks of 32 KiB; < 0: no pool (every overflow costs another pass) */,
        GRT_OPT_OVF_ENTRIES = 22       /* per-lane capacity of a bag actually used, 1..96 (0 = default 96) */,
        GRT_OPT_MAX_ITERS = 23         /* step watchdog of the tile kernel (0 = default 2^21): a tile over it gives up on its rays
                                          and sets the sticky error word */,

@@ -74,12 +74,12 @@ def test_views_share_one_scene_and_render_the_same_frames():
 
 def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
     """The pool of window-overflow bags: sized from the demand of the frames before; with too few chunks (or none) the
-    tiles that find it empty drop events for good and go again (grt_render_tile.hip: `chunk = kNoRoot - 1`) — more
+    tiles that find it empty drop events for good and go again (grt_render_tile.hip: `dry`) — more
     passes, the same bytes."""
     acts, p, sc = _dense_cluster_camera()
     tr = grt.Tracer(0)
     tr.upload(acts)
-    tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)  # whole tiles: one chunk per tile at most (a tile launched as part waves takes one per part)
+    tr.set_option(grt.OPT_TILE_PARTS4_PCT, 0)  # whole tiles: three chunks per tile at most (a tile launched as part waves takes them per part)
     tr.set_option(grt.OPT_COUNTERS, 1)
     ref8, reff = tr.render(p, want_f32=True)
     ref8, reff = ref8.clone(), reff.clone()
@@ -87,13 +87,14 @@ def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
     n_tiles = (128 // 8) * (96 // 8)
     tr.render(p); tr.sync(); tr.render(p); tr.sync()
     m = tr.memory_info()
-    assert 0 < m["overflow_demand"] <= n_tiles              # the demand was read back behind the frames ...
-    assert m["overflow_demand"] <= m["overflow_chunks"] <= n_tiles  # ... and the pool covers it, never more than a chunk per tile
+    assert 0 < m["overflow_demand"] <= 3 * n_tiles          # the demand was read back behind the frames ...
+    assert m["overflow_demand"] <= m["overflow_chunks"] <= 3 * n_tiles  # ... and the pool covers it, never more than three chunks per tile
+    assert m["overflow_pool_bytes"] == m["overflow_chunks"] * 32 * 64 * 16
     a8, af = tr.render(p, want_f32=True)
     c1 = tr.counters()                                      # steady state: no tile finds the pool empty
     assert (a8 == ref8).all() and (af == reff).all() and c1["rounds"] <= c0["rounds"]
     rounds = {}
-    for chunks in (2, -1):
+    for chunks in (6, -1):  # (two full bags: a tile without a hint takes three chunks in a row)
         tr.set_option(grt.OPT_OVF_CHUNKS, chunks)
         for _ in range(2):
             a8, af = tr.render(p, want_f32=True)
@@ -102,7 +103,7 @@ def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
             assert c["stall_exits"] == 0 and c["hit_evals"] == c0["hit_evals"]
         rounds[chunks] = c["rounds"]
         assert tr.memory_info()["overflow_chunks"] == max(chunks, 0)
-    assert rounds[-1] > rounds[2] > c1["rounds"]            # fewer bags, more passes
+    assert rounds[-1] > rounds[6] > c1["rounds"]            # fewer bags, more passes
     tr.set_option(grt.OPT_OVF_CHUNKS, 0)
     tr.render(p); tr.sync()
     a8, af = tr.render(p, want_f32=True)
@@ -111,6 +112,52 @@ def test_overflow_pool_follows_demand_and_tolerates_exhaustion():
     compare(reff, ref_f32, ref8, ref_u8)
     assert rc["hit_evals"] == c0["hit_evals"]
     tr.close(); sc.close()
+
+
+def test_tiles_with_shallow_bags_take_one_chunk_of_the_pool():
+    """The pool is handed out in chunks of 32 entries x 64 rays.  A tile takes three in a row (a full 96-entry bag per ray) —
+    or ONE, when no bag of it held more than 20 entries in the frame before: the tile kernel notes deep bags in the lowest
+    bit of the tile's cost word, the launch order hands the size class back in the part field of a whole tile's entry
+    (grt_render_tile.hip kBagKeep, grt_bvh.hip k_cost_order_parts).  Same frames whatever the size class (a tile that
+    outgrows one chunk prunes and drops like any full bag and goes again), a smaller demand once the classes are known, and
+    a camera that moves — tiles changing class every frame — renders what a tracer without feedback renders."""
+    acts, p, sc, op, center = make_scene(37, 60000, 384, 256, scale_boost=0.3)
+    n_tiles = (384 // 8) * (256 // 8)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    ref8, reff = tr.render(p, want_f32=True)   # first frame: no costs yet, three chunks for every tile that overflows
+    ref8, reff = ref8.clone(), reff.clone()
+    c0 = tr.counters()
+    tr.sync(); tr.render(p); tr.sync()
+    first = tr.memory_info()["overflow_demand"]
+    assert 0 < first <= 3 * n_tiles
+    for _ in range(10):
+        a8, af = tr.render(p, want_f32=True)
+        assert (a8 == ref8).all() and (af == reff).all()
+        tr.sync()
+    c1 = tr.counters()
+    assert c1["hit_evals"] == c0["hit_evals"] and c1["stall_exits"] == 0
+    m = tr.memory_info()
+    assert 0 < m["overflow_demand"] < first            # some tiles live in one chunk now ...
+    d = m["overflow_demand"]
+    assert d <= m["overflow_chunks"] <= (d + d // 4 + 64) * 6 // 5  # ... and the pool follows the demand, down as well as up
+    ref_u8, ref_f32, rc = sc.render(op, threads=8)
+    compare(reff, ref_f32, ref8, ref_u8)
+    assert rc["hit_evals"] == c0["hit_evals"]
+    # a moving camera against a tracer without feedback (no launch order: every tile takes three chunks)
+    plain = grt.Tracer(0)
+    plain.upload(acts)
+    plain.set_option(grt.OPT_FEEDBACK, 0)
+    for k in range(6):
+        ang = 0.06 * (k + 1)
+        eye = (float(center[0] + 3.0 * np.sin(ang)), float(center[1] + 0.4), float(center[2] + 3.0 * np.cos(ang)))
+        q = grt.default_params(384, 256, center, eye=eye)
+        a8, af = tr.render(q, want_f32=True)
+        b8, bf = plain.render(q, want_f32=True)
+        assert (a8 == b8).all() and (af == bf).all(), k
+    tr.check(); plain.check()
+    tr.close(); plain.close(); sc.close()
 
 
 def test_full_bags_of_equal_keys_are_truncated():

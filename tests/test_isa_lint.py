@@ -185,11 +185,43 @@ def test_exec_prologue_repair_refuses_what_depends_on_its_place():
     with pytest.raises(V.ExecPrologueError, match="not a VGPR spill store"):
         V.repair(reload)
     # a spill store whose register a lane move BEHIND it (staying in front of the restore) writes, or with a vmcnt wait behind it
-    for tail, why in (("\tv_writelane_b32 v115, s4, 2\n", "names a moved register"), ("\ts_waitcnt vmcnt(0)\n", "vector-memory counter")):
+    # that would stay behind together with something else
+    for tail, why in (("\tv_writelane_b32 v115, s4, 2\n", "names a moved register"),
+                      ("\ts_waitcnt vmcnt(0)\n\tv_readlane_b32 s4, v9, 1\n", "vector-memory counter")):
         t = ".LBB1_2:\n\tscratch_store_dword off, v115, off      ; 4-byte Folded Spill\n" + tail + "\ts_or_b64 exec, exec, s[12:13]\n"
         assert len(V.lint(t)) == 1
         with pytest.raises(V.ExecPrologueError, match=why):
             V.repair(t)
+
+
+def test_exec_prologue_repair_moves_a_tail_of_stores_and_waits_as_one_piece():
+    # round 5 (the bags' chunks): spill stores interleaved with the waits for the loads whose results they spill.  From the first
+    # store to the restore there is nothing but stores, s_waitcnt and s_nop: the tail goes behind the restore in its own order —
+    # the same as hoisting the restore over it
+    t = """\
+\ts_cbranch_execz .LBB1_284
+.LBB1_283:
+\tglobal_load_dwordx4 v[6:9], v[2:3], off offset:16
+\ts_nop 0
+\tglobal_load_dwordx4 v[2:5], v[2:3], off
+.LBB1_284:
+\ts_nop 0
+\tscratch_store_dword off, v102, off offset:24 ; 4-byte Folded Spill
+\ts_waitcnt vmcnt(4)
+\tscratch_store_dword off, v93, off offset:20 ; 4-byte Folded Spill
+\ts_waitcnt vmcnt(2)
+\tscratch_store_dword off, v101, off offset:16 ; 4-byte Folded Spill
+\ts_or_b64 exec, exec, s[12:13]
+\ts_mov_b32 s30, s59
+"""
+    assert len(V.lint(t)) == 3
+    fixed, moved = V.repair(t)
+    assert V.lint(fixed) == [] and len(moved) == 5
+    L = [l.split(";")[0].strip() for l in fixed.split("\n")]
+    r = L.index("s_or_b64 exec, exec, s[12:13]")
+    assert L[r - 1] == "s_nop 0" and L[r - 2] == ".LBB1_284:"
+    assert L[r + 1:r + 7] == ["scratch_store_dword off, v102, off offset:24", "s_waitcnt vmcnt(4)", "scratch_store_dword off, v93, off offset:20",
+                              "s_waitcnt vmcnt(2)", "scratch_store_dword off, v101, off offset:16", "s_mov_b32 s30, s59"]
 
 
 def test_exec_prologue_lint_is_structural_at_join_labels():
@@ -265,7 +297,8 @@ def test_isa_budget_of_the_render_kernels():
     assert c3["spill_instructions_in_loops"] <= 1 and c3["spill_instructions"] <= 12 and c3["scratch_bytes"] <= 32, c3
     # (SGPR-spill traffic inside loops predicts the frame: 146 / 171 / 210 v_readlane + v_writelane in loops = -2.7 % / 0 / +3.6 % on C3,
     #  profiles/r04_experiments_log.md 10)
-    assert c3["lane_moves"] <= 165 and c3["lane_moves_in_loops"] <= 145 and c3["spilled_sgprs"] <= 8 and c3["instructions"] <= 5200, c3
+    # (spilled SGPRs: 6 until the bags' size classes, 12 with them — two more values live per tile; the frame did not move: r05 log 7)
+    assert c3["lane_moves"] <= 165 and c3["lane_moves_in_loops"] <= 145 and c3["spilled_sgprs"] <= 12 and c3["instructions"] <= 5200, c3
     # the mesh frame's stages (C4): guarded where they stand (VERDICT r04 asked for <= 200 / <= 20 / <= 300; not reached this round —
     # what is asserted is that they do not get WORSE unseen, the uninstrumented instantiations that frames run)
     for name, k in tile.items():
