@@ -15,6 +15,7 @@ import glob
 import json
 import os
 import re
+import subprocess
 import sys
 
 import pytest
@@ -250,6 +251,29 @@ def test_exec_prologue_lint_is_structural_at_join_labels():
     # ... and `s_mov_b64 exec, sN` with sN formed in the block itself is the expanded s_and_saveexec_b64 of an if: it narrows EXEC
     narrow = "\ts_cbranch_execz .LBB6_280\n.LBB6_280:\n\tv_mov_b32_e32 v82, 0\n\ts_mov_b64 s[0:1], exec\n\ts_and_b64 s[0:1], s[0:1], s[4:5]\n\ts_mov_b64 exec, s[0:1]\n"
     assert V.lint(narrow) == []
+
+
+def test_the_recorded_reproducer_still_shows_the_compiler_defect(tmp_path):
+    """profiles/r05_exec_prologue_repro: one kernel's optimised IR that the image's `llc -O3` turns into spill stores in front of
+    a join block's EXEC restore.  While this passes the build's post-pass is needed; when it fails the tool chain was fixed."""
+    import gzip
+    import shutil
+    llc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "llc")
+    if not os.path.exists(llc):
+        pytest.skip("no llc")
+    rep = os.path.join(ROOT, "profiles", "r05_exec_prologue_repro")
+    ll = tmp_path / "r.ll"
+    with gzip.open(os.path.join(rep, "k_render_tile_counted_sh_pieces.ll.gz"), "rb") as f, open(ll, "wb") as g:
+        shutil.copyfileobj(f, g)
+    out = tmp_path / "r.s"
+    subprocess.run([llc, "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O3", str(ll), "-o", str(out)], check=True)
+    text = open(out).read()
+    bad = V.lint(text)
+    assert bad and all("Folded Spill" in t for _, t in bad), bad
+    fixed, moved = V.repair(text)  # ... and the build's repair takes this very case (stores and the waits between them, as one piece)
+    assert V.lint(fixed) == [] and len(moved) >= len(bad)
+    r = subprocess.run([sys.executable, os.path.join(rep, "check.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Folded Spill" in r.stdout
 
 
 def _built_asm():
