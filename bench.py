@@ -411,6 +411,12 @@ def main():
     for t in trs:
         t.check()  # raises when a wave gave up on live rays anywhere in the run (sticky device error word)
     mem = [t.memory_info() for t in trs]
+    # (the overflow pool follows the median demand of the last eight frames it has READ BACK, and a loop that queues its frames without
+    #  waiting reads few: ten more synchronised standing frames on slot 0, outside every timed region, show what the slot settles at)
+    for _ in range(10):
+        one_frame()
+        tr.sync()
+    mem_settled = tr.memory_info()
     el = torch.tensor([elapsed, other[0] if other else 0.0], dtype=torch.float64, device=dev)
     km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -460,11 +466,14 @@ def main():
                        "forced_collective": force or None,
                        "frames_in_flight": D,
                        "device_memory_bytes": {"scene": mem[0]["scene_bytes"], "frame_slots": [m["slot_bytes"] for m in mem],
+                                               "frame_slot_0_settled": mem_settled["slot_bytes"],
                                                "overflow_pool_chunks": [m["overflow_chunks"] for m in mem],
                                                "overflow_demand_chunks": [m["overflow_demand"] for m in mem],
                                                "total": mem[0]["scene_bytes"] + sum(m["slot_bytes"] for m in mem),
-                                               "note": "one scene shared by all frame slots (views); the pool of window-overflow bags "
-                                                       "(96 KiB chunks) follows the demand of the frames before"},
+                                               "note": "one scene shared by all frame slots (views); the pool of window-overflow bags (32 KiB chunks, "
+                                                       "one to three per tile that overflows) follows the median demand of the last eight frames READ BACK, "
+                                                       "both ways; frame_slots = as the legs of this run left them (cold frames, a moving camera, loops that "
+                                                       "queue frames without waiting), frame_slot_0_settled = slot 0 after ten more synchronised standing frames"},
                        "value_sync": None if value_sync is None else round(value_sync, 3),
                        "value_pipelined": None if value_pipe is None else round(value_pipe, 3),
                        "pipelined_frames_in_flight": D if D > 1 else (D_other or None),

@@ -542,12 +542,14 @@ static void free_meshes(grt_ctx* c)
 }
 
 // everything a frame slot owns (a view has nothing else)
+static void reap_old_pools(grt_ctx* c, bool force);
 static void free_slot_state(grt_ctx* c)
 {
     (void)hipFree(c->d_erec); (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch); (void)hipFree(c->d_qparts); (void)hipFree(c->d_qpcount);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
+    reap_old_pools(c, true);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
     if (c->h_ovf_used) (void)hipHostFree(c->h_ovf_used);
@@ -641,6 +643,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_STATIC_SHARP) { c->opt_static_sharp = value != 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_ORDER_MULTI_MIN) { c->opt_order_multi_min = std::max(1, value); }
     else if (option == GRT_OPT_MESH_PARTS) { c->opt_mesh_parts = value != 0; c->cost_valid = false; c->order_ready = false; }
+    else if (option == GRT_OPT_OVF_CLASSES) { c->opt_ovf_classes = value ? 1 : 0; c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_QUAD_PARTS) { c->opt_quad_parts = std::max(0, value); c->cost_valid = false; c->order_ready = false; } // (2: whatever the launch's size; > 2: and that many parts at most — testing)
     else if (option == GRT_OPT_TILE_PARTS_LOAD_PCT) { c->opt_tile_parts_load_pct = std::min(100000, std::max(0, value)); c->cost_valid = false; c->order_ready = false; }
     else if (option == GRT_OPT_TILE_PRIO_DIV) { c->opt_tile_prio = std::max(0, value); }
@@ -1123,7 +1126,7 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         const bool quad = quad_parts_ok(c, n_units) && c->d_qparts;
         int rcp = order_units_with_parts(cost_src, c->d_cost, c->d_order, n_units, cap, (uint32_t)c->opt_tile_parts2_pct,
                                          quad ? quad_pct4(c, n_units) : (uint32_t)c->opt_tile_parts4_pct, (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, d_zero, c->d_ord_scratch,
-                                         (uint32_t)c->opt_order_multi_min, true, s, &c->err);
+                                         (uint32_t)c->opt_order_multi_min, c->opt_ovf_classes ? 1u : 0u, s, &c->err);
         if (rcp == GRT_OK) {
             c->order_launch = n_units + cap;
             c->qparts_valid = false;
@@ -1239,7 +1242,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             const uint32_t cap = parts_extra_cap(n_units);
             rc = order_units_with_parts(src, c->d_cost_dil, c->d_order, n_units, cap, 0u, (uint32_t)c->opt_cold_parts_pct,
                                         (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, nullptr, c->d_ord_scratch,
-                                        (uint32_t)c->opt_order_multi_min, false /* (particle counts, not cost words) */, s, &c->err);
+                                        (uint32_t)c->opt_order_multi_min, c->opt_ovf_classes ? 2u /* (particle counts, not cost words) */ : 0u, s, &c->err);
             if (rc == GRT_OK) {
                 c->order_launch = n_units + cap; a.n_launch = c->order_launch;
                 c->qparts_valid = false;
@@ -1269,35 +1272,60 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
 }
 
 // The tile kernel's pool of window-overflow bags, in chunks of kTileOvfChunkBytes = 32 KiB (32 entries x 64 lanes): a tile that
-// overflows takes one, and up to two more as its fullest bag grows (grt_render_tile.hip).  A tile that finds the pool empty falls
-// back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the default 1 M scene and cost that frame 12 %, and
-// on the needle scene C3a a pool of 3/8 of the tiles made the first frames 2.3 x slower).  Round 2 held a full bag for EVERY tile
-// of the launch for good (3.1 GB at 1080p, 12.4 GB at 4K, per frame slot); rounds 3-4 sized the pool from the largest demand
-// ever seen, in whole 96-entry bags (1.3 GB at 1080p).  Now the pool follows the DEMAND both ways: every frame's chunk counter is
-// read back behind it (pinned word, no sync; the device keeps the peak between two reads), the last eight readings are kept, and
-// the pool is 1.25 x their MEDIAN + 64 — re-made when the median comes within 10 % of it, or when it is more than 1.2 x what
-// that rule asks for (a re-size waits for the device: the band keeps a drifting demand from paying that every frame).  The first frame of a
-// launch geometry still gets three chunks per tile (or what a sibling frame slot of the same scene has learnt).  An allocation
-// that fails is retried at half the size down to nothing: rendering never fails for want of an optimisation buffer.
-static uint32_t overflow_demand_median(const grt_ctx* c)
+// overflows takes one to three in a row, by how deep its bags got in the frame before (grt_render_tile.hip kSub).  A tile that
+// finds the pool empty falls back to another pass (never wrong; a pool for a quarter of the tiles ran dry on the default 1 M scene and
+// cost that frame 12 %, and on the needle scene C3a a pool of 3/8 of the tiles made the first frames 2.3 x slower).  Round 2 held a full
+// bag for EVERY tile of the launch for good (3.1 GB at 1080p, 12.4 GB at 4K, per frame slot); rounds 3-4 sized the pool from the
+// largest demand ever seen, in whole 96-entry bags (1.3 GB at 1080p).  Now the pool follows the DEMAND both ways: every frame's chunk
+// counter is read back behind it (pinned word, no sync; the device keeps the peak between two reads) and the last eight readings are
+// kept.  The pool is 1.25 x their MEDIAN + 64 (one cold frame — a camera cut: no size classes, every tile asks for more — does not move
+// it); it GROWS when the median comes within 10 % of it and SHRINKS when it is more than 1.5 x what the LARGEST of the eight would ask
+// for (so a spike only delays a shrink, and a demand that wanders does not re-make the pool every frame).  A re-size does not wait for
+// the device: the new pool is allocated beside the old one, which is freed once the frames that may use it have drained (hipFree
+// synchronises: it is called when nothing of this scene is in flight, or at the latest when a third pool would pile up).  The first
+// frame of a launch geometry still gets three chunks per tile (or what a sibling frame slot of the same scene has learnt).  An
+// allocation that fails is retried at half the size down to nothing and not asked for again: rendering never fails for want of an
+// optimisation buffer.
+static void overflow_demand_stats(const grt_ctx* c, uint32_t* median, uint32_t* largest)
 {
-    if (!c->ovf_hist_n) return 0u;
+    *median = *largest = 0u;
+    if (!c->ovf_hist_n) return;
     uint32_t v[8];
     const uint32_t n = std::min(c->ovf_hist_n, 8u);
     for (uint32_t i = 0; i < n; i++) v[i] = c->ovf_hist[i];
     std::sort(v, v + n);
-    return v[n / 2u]; // (the upper median of an even count)
+    *median = v[n / 2u]; // (the upper median of an even count)
+    *largest = v[n - 1u];
 }
 
-static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
+// old pools whose last users may still run: freed when their event has passed and no frame of the scene is in flight (force: now)
+static void reap_old_pools(grt_ctx* c, bool force)
+{
+    if (c->ovf_old.empty()) return;
+    if (!force && c->ovf_old.size() < 2u && sibling_frames_in_flight(c)) return;
+    for (size_t i = 0; i < c->ovf_old.size();) {
+        auto& o = c->ovf_old[i];
+        if (force || c->ovf_old.size() >= 2u || hipEventQuery(o.second) == hipSuccess) {
+            if (hipEventQuery(o.second) != hipSuccess) (void)hipEventSynchronize(o.second);
+            (void)hipFree(o.first);
+            (void)hipEventDestroy(o.second);
+            c->ovf_old.erase(c->ovf_old.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+}
+
+static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
 {
     grt_ctx* sc = scene_of(c);
+    reap_old_pools(c, false);
     if (c->ovf_units != n_tiles) { c->ovf_hist_n = 0; c->ovf_demand = 0; c->ovf_short = false; c->ovf_units = n_tiles; c->ovf_stale = c->ovf_pending; } // another launch geometry: start over
     if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
         if (!c->ovf_stale) { // (a reading asked for under the geometry before says nothing about this one)
             c->ovf_hist[c->ovf_hist_n % 8u] = std::max(*c->h_ovf_used, 1u);
             c->ovf_hist_n++;
-            c->ovf_demand = overflow_demand_median(c);
+            overflow_demand_stats(c, &c->ovf_demand, &c->ovf_demand_max);
             sc->ovf_hint_units = c->ovf_units;
             sc->ovf_hint = c->ovf_demand;
         }
@@ -1312,17 +1340,34 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
         want = c->opt_ovf_chunks > 0 ? (uint32_t)c->opt_ovf_chunks : 0u;
         resize = c->ovf_chunks != want;
     } else {
-        const uint32_t d = c->ovf_demand ? c->ovf_demand : ((sc->ovf_hint_units == n_tiles) ? sc->ovf_hint : 0u);
+        const bool own = c->ovf_demand != 0u;
+        const uint32_t d = own ? c->ovf_demand : ((sc->ovf_hint_units == n_tiles) ? sc->ovf_hint : 0u);
+        const uint32_t dmax = own ? c->ovf_demand_max : d;
         if (d == 0u) { // nothing known yet
             want = most;
             resize = c->ovf_chunks < want && !c->ovf_short;
         } else {
-            want = std::min(most, d + d / 4u + 64u);
-            resize = (c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short) || c->ovf_chunks > want + want / 5u;
+                want = std::min(most, d + d / 4u + 64u);
+            const uint32_t keep = std::min(most, dmax + dmax / 4u + 64u); // what the largest recent demand would ask for
+            const bool grow = c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short;
+            const bool shrink = c->ovf_chunks > keep + keep / 2u;
+            resize = grow || shrink;
+            if (shrink && !grow) want = keep;
         }
     }
     if (resize) {
-        if (c->d_ovf) { (void)hipDeviceSynchronize(); (void)hipFree(c->d_ovf); } // a frame in flight may still use it
+        if (c->d_ovf) { // frames in flight may still use it: it goes when they have drained
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, s) == hipSuccess) {
+                c->ovf_old.emplace_back(c->d_ovf, ev);
+            } else {
+                if (ev) (void)hipEventDestroy(ev);
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+                (void)hipFree(c->d_ovf);
+            }
+            reap_old_pools(c, false);
+        }
         c->d_ovf = nullptr;
         c->ovf_chunks = 0;
         for (uint32_t n = want; n >= 1u; n /= 2u) {
@@ -1330,6 +1375,7 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles)
             c->ovf_short = true; // (the memory is not there: growing is not tried again for this launch geometry)
             (void)hipGetLastError(); // out of memory is not an error of the frame: a smaller pool, or none
             c->d_ovf = nullptr;
+            reap_old_pools(c, true); // (what waits to be freed may be what is missing)
             if (c->opt_ovf_chunks > 0) break;
         }
     }
@@ -1423,8 +1469,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     }
     a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
     a.ovf_entries = c->opt_ovf_entries > 0 ? (uint32_t)c->opt_ovf_entries : kTileOvfEntries;
+    { static const char* e0 = getenv("GRT_OVF_BUMP"); a.ovf_bump = e0 ? (uint32_t)atoi(e0) : (c->launch_order_matched ? 0u : 1u); }
     if (tile_kernel) {
-        int rco = size_overflow_pool(c, a.n_blocks * 4u);
+        int rco = size_overflow_pool(c, a.n_blocks * 4u, s);
         if (rco != GRT_OK) return rco;
         if (!c->d_ovf_next) { // [0] next free chunk, [1] running peak of the demand (k_frame_tail)
             CHK(c, hipMalloc(&c->d_ovf_next, 2 * sizeof(uint32_t)));

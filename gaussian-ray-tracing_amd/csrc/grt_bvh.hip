@@ -574,13 +574,15 @@ __global__ __launch_bounds__(1024) void k_cost_order(const uint32_t* cost, uint3
 }
 
 // The chunks of the overflow pool a whole tile takes in the frame this order is made for, from the two lowest bits of its cost word
-// (grt_render_tile.hip kBagKeep1 / kBagKeep2: how full the fullest bag of any of its rays got): 1, 2, or 0 = a full bag (three) —
-// also for a tile without a cost, and when the costs are not the tile kernel's words at all (the cold frame's particle counts)
+// (grt_render_tile.hip kBagKeep1 / kBagKeep2: how full the fullest bag of any of its rays got): 1, 2 or 3 (a full bag); 0 = not known —
+// a tile without a cost, or costs that are not the tile kernel's words at all (the cold frame's particle counts): the launch decides
+// (RenderArgs::ovf_cls0).  enabled = 0 (GRT_OPT_OVF_CLASSES off): a full bag for everyone
 __device__ __forceinline__ uint32_t bag_class(uint32_t enabled, uint32_t cost_word)
 {
-    if (!enabled || cost_word == 0u) return 0u;
+    if (!enabled) return 3u;
+    if (cost_word == 0u) return 0u;
     const uint32_t d = cost_word & 3u;
-    return d == 0u ? 1u : (d == 1u ? 2u : 0u);
+    return d == 0u ? 1u : (d == 1u ? 2u : 3u);
 }
 
 // The same order with the heaviest tiles launched as PARTS (tile kernel, camera rays without meshes).  A frame takes at least
@@ -722,8 +724,8 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* cost,
                 const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
                 const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
                 const uint32_t pos = atomicAdd(&cursor[b], parts);
-                // (a whole tile's part field carries its bags' size class: the chunks of the pool it takes, 0 = a full bag)
-                if (code == 0u) order[pos] = i | (bag_class(bag_classes, rv[k]) << 28);
+                // (a whole tile's part field carries its bags' size class: the chunks of the pool it takes, 0 = not known)
+                if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : rv[k]) << 28);
                 else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
             }
             __syncthreads();
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint
             const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
             const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
             const uint32_t pos = atomicAdd(&cursor[b], parts);
-            if (code == 0u) order[pos] = i | (bag_class(bag_classes, rw) << 28); // (the bags' size class: k_cost_order_parts)
+            if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : rw) << 28); // (the bags' size class: k_cost_order_parts)
             else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
         }
         __syncthreads();
@@ -962,10 +964,10 @@ int quad_part_list(uint32_t* d_order, uint32_t n_entries, uint32_t* d_list, uint
 
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
-                           uint32_t multi_min, bool bag_classes, hipStream_t stream, std::string* err)
+                           uint32_t multi_min, uint32_t bag_classes /* 0: a full bag for every tile; 1: d_cost_raw holds the tile kernel's cost words, their two lowest bits are the bags' depth; 2: it does not (nothing known) */, hipStream_t stream, std::string* err)
 {
     if (n == 0) return GRT_OK;
-    const uint32_t cls = bag_classes ? 1u : 0u; // (d_cost_raw holds cost words of the tile kernel: their lowest bit is the bags' size class)
+    const uint32_t cls = bag_classes;
     if (d_scratch && n >= multi_min) { // several workgroups, four phases (see k_ord_a)
         uint32_t per = 2048u; // units per workgroup: two runs of 1024
         if ((n + per - 1u) / per > kOrdMaxGroups) per = (((n + kOrdMaxGroups - 1u) / kOrdMaxGroups) + 1023u) & ~1023u;

@@ -119,6 +119,7 @@ struct RenderArgs {
     uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
     uint32_t ovf_chunks;     // chunks in the pool
     uint32_t ovf_entries;    // per-lane capacity of a bag actually used (<= kTileOvfEntries; smaller only in tests)
+    uint32_t ovf_bump;       // 1: size classes move up by one chunk (the launch order was made from another view's costs), else 0
     // always-on failure signal: a wave that has to give up on a ray (watchdog, stack guard, two passes without progress)
     // ORs its reason into this device word, whatever the kernel variant; grt_sync / grt_get_counters report it
     uint32_t* err_word;
@@ -221,7 +222,7 @@ int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uin
 // (d_scratch: order_scratch_bytes() of device memory, zeroed once; launches of multi_min units and more are ordered by several workgroups)
 int order_units_with_parts(const uint32_t* d_cost_order, const uint32_t* d_cost_raw, uint32_t* d_order, uint32_t n, uint32_t extra_cap,
                            uint32_t pct2, uint32_t pct4, uint32_t pct_load, uint32_t resident_waves, uint32_t* d_zero, uint32_t* d_scratch,
-                           uint32_t multi_min, bool bag_classes, hipStream_t stream, std::string* err);
+                           uint32_t multi_min, uint32_t bag_classes, hipStream_t stream, std::string* err);
 uint32_t order_scratch_bytes();
 // the first kQuadListCap four-way part entries of a launch order (n_entries of them incl. padding), in order, listed in d_list and re-coded
 // 2 -> 3 in the order itself; d_count[0] = how many
@@ -270,6 +271,8 @@ struct grt_ctx {
     uint32_t ovf_hist_n = 0;
     bool ovf_stale = false;       // the reading on its way was asked for under another launch geometry
     bool ovf_short = false;       // an allocation of the size wanted failed
+    uint32_t ovf_demand_max = 0;  // ... and the largest of those readings
+    std::vector<std::pair<float4*, hipEvent_t>> ovf_old; // pools replaced while frames that may use them were in flight
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for
     uint32_t ovf_hint = 0, ovf_hint_units = 0; // scene context: the demand its frame slots have seen (a new slot starts from it)
     int opt_tile_parts2_pct = 0, opt_tile_parts4_pct = 60, opt_tile_parts_load_pct = 75; // GRT_OPT_TILE_PARTS2_PCT / _PARTS4_PCT / _PARTS_LOAD_PCT
@@ -277,6 +280,7 @@ struct grt_ctx {
     int opt_static_sharp = 1;     // GRT_OPT_STATIC_SHARP: a view that stood still for two frames is ordered by its tiles' own costs, not the dilated map
     int opt_order_multi_min = 16384; // GRT_OPT_ORDER_MULTI_MIN: launches of this many tiles and more are ordered by several workgroups
     int opt_mesh_parts = 1;       // GRT_OPT_MESH_PARTS: heavy tiles of a MESH frame's primary stage run as part waves too
+    int opt_ovf_classes = 1;      // GRT_OPT_OVF_CLASSES: tiles take one to three chunks of the overflow pool by how deep their bags got (0: three)
     int opt_quad_parts = 1;       // GRT_OPT_QUAD_PARTS: four-way parts of camera-ray frames (no meshes, no pieces) run on the quad kernel
     bool parts_ok = false;        // this launch may run heavy tiles as parts (tile kernel, camera rays, no meshes)
     uint32_t order_launch = 0;    // entries of d_order when it holds parts (units + extra + padding); 0 = one entry per unit

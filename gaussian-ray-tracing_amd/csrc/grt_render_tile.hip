@@ -606,10 +606,13 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         // (QUAD: a ray's four bags TOGETHER hold what one bag of the camera-ray kernel holds.  The capacity is a cut-off, not just room:
         //  a ray whose bag is full stops wanting what lies beyond, the tile's reach shrinks with it and the frontier stays clear of far
         //  entries — with four full-size bags a quadrant of a cluster core went on for 242 steps where the part wave took 164)
-        // (a whole tile whose bags stayed shallow in the frame before — part field 1 or 2 of its order entry — lives in one or two chunks)
-        const uint32_t cls_ = (MODE == 0 && a.order && (ue >> 30) == 0u) ? ((ue >> 28) & 3u) : 0u; // chunks the tile lives in (0: a full bag)
-        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : (cls_ ? min(a.ovf_entries, cls_ * kSub) : a.ovf_entries);
-        const uint32_t prune_room = QUAD ? kPruneRoom / 4u : (cls_ ? kSub / 4u : kPruneRoom);
+        // (a whole tile whose bags stayed shallow in the frame before — part field 1 or 2 of its order entry — lives in one or two chunks;
+        //  part field 0: a tile without a cost word takes a full bag.  a.ovf_bump = 1: the order was made from the costs of ANOTHER view —
+        //  a camera in motion — and every class moves up by one: what was shallow under the last view may not be under this one)
+        const uint32_t fld_ = (MODE == 0 && a.order && (ue >> 30) == 0u) ? ((ue >> 28) & 3u) : 3u;
+        const uint32_t cls_ = fld_ ? min(fld_ + a.ovf_bump, 3u) : 3u; // chunks the tile lives in: 1..3 (3: a full bag)
+        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : min(a.ovf_entries, cls_ * kSub);
+        const uint32_t prune_room = QUAD ? kPruneRoom / 4u : (cls_ < 3u ? kSub / 4u : kPruneRoom);
         const uint32_t ready_min = SINGLE ? 1u : a.tile_ready_min; // lanes with a final event before a compositing sweep starts
         // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
         const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;

@@ -66,6 +66,7 @@ OPT_ORDER_MULTI_MIN = 30
 OPT_STATIC_SHARP = 31
 OPT_COLD_PARTS_PCT = 32
 OPT_QUAD_PARTS = 33
+OPT_OVF_CLASSES = 34
 ERR_LIMIT = -5
 KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERNEL_TILE = 0, 1, 2, 3, 4, 5
 

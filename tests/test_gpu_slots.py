@@ -141,7 +141,11 @@ def test_tiles_with_shallow_bags_take_one_chunk_of_the_pool():
     m = tr.memory_info()
     assert 0 < m["overflow_demand"] < first            # some tiles live in one chunk now ...
     d = m["overflow_demand"]
-    assert d <= m["overflow_chunks"] <= (d + d // 4 + 64) * 6 // 5  # ... and the pool follows the demand, down as well as up
+    assert d <= m["overflow_chunks"] <= (first + first // 4 + 64)  # ... and the pool never above what the cold frame asked for
+    for _ in range(8):                                  # ... eight more readings: the cold frame has left the history, the pool follows down
+        tr.render(p); tr.sync()
+    m = tr.memory_info(); d = m["overflow_demand"]
+    assert d < first and d <= m["overflow_chunks"] <= (d + d // 4 + 64) * 3 // 2
     ref_u8, ref_f32, rc = sc.render(op, threads=8)
     compare(reff, ref_f32, ref8, ref_u8)
     assert rc["hit_evals"] == c0["hit_evals"]
