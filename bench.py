@@ -413,9 +413,10 @@ def main():
     mem = [t.memory_info() for t in trs]
     # (the overflow pool follows the median demand of the last eight frames it has READ BACK, and a loop that queues its frames without
     #  waiting reads few: ten more synchronised standing frames on slot 0, outside every timed region, show what the slot settles at)
-    for _ in range(10):
-        one_frame()
-        tr.sync()
+    if extra:  # (not in the runs the profiles are taken from: their last K dispatches are the timed loop)
+        for _ in range(10):
+            one_frame()
+            tr.sync()
     mem_settled = tr.memory_info()
     el = torch.tensor([elapsed, other[0] if other else 0.0], dtype=torch.float64, device=dev)
     km = torch.tensor([float(np.mean(kern_ms))], dtype=torch.float64, device=dev)

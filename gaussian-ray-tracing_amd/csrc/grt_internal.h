@@ -271,6 +271,8 @@ struct grt_ctx {
     uint32_t ovf_hist_n = 0;
     bool ovf_stale = false;       // the reading on its way was asked for under another launch geometry
     bool ovf_short = false;       // an allocation of the size wanted failed
+    bool ovf_fold = true;         // this frame's demand counts as a reading (not a cold frame of a kind that has size classes)
+    bool order_classes = false;   // the launch order in d_order carries size classes
     uint32_t ovf_demand_max = 0;  // ... and the largest of those readings
     std::vector<std::pair<float4*, hipEvent_t>> ovf_old; // pools replaced while frames that may use them were in flight
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for

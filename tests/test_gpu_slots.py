@@ -130,22 +130,26 @@ def test_tiles_with_shallow_bags_take_one_chunk_of_the_pool():
     ref8, reff = ref8.clone(), reff.clone()
     c0 = tr.counters()
     tr.sync(); tr.render(p); tr.sync()
-    first = tr.memory_info()["overflow_demand"]
-    assert 0 < first <= 3 * n_tiles
+    assert tr.memory_info()["overflow_demand"] == 0     # (a cold frame's demand — a full bag for every tile — is not a reading)
     for _ in range(10):
         a8, af = tr.render(p, want_f32=True)
         assert (a8 == ref8).all() and (af == reff).all()
         tr.sync()
     c1 = tr.counters()
     assert c1["hit_evals"] == c0["hit_evals"] and c1["stall_exits"] == 0
-    m = tr.memory_info()
-    assert 0 < m["overflow_demand"] < first            # some tiles live in one chunk now ...
-    d = m["overflow_demand"]
-    assert d <= m["overflow_chunks"] <= (first + first // 4 + 64)  # ... and the pool never above what the cold frame asked for
-    for _ in range(8):                                  # ... eight more readings: the cold frame has left the history, the pool follows down
-        tr.render(p); tr.sync()
     m = tr.memory_info(); d = m["overflow_demand"]
-    assert d < first and d <= m["overflow_chunks"] <= (d + d // 4 + 64) * 3 // 2
+    assert 0 < d <= m["overflow_chunks"] <= (d + d // 4 + 64) * 3 // 2  # the pool follows the demand
+    full = grt.Tracer(0)                               # the same frames with a full bag for every tile that overflows (round 4)
+    full.upload(acts)
+    full.set_option(grt.OPT_OVF_CLASSES, 0)
+    for _ in range(6):
+        b8, bf = full.render(p, want_f32=True)
+        full.sync()
+    assert (b8 == ref8).all() and (bf == reff).all()
+    mf = full.memory_info()
+    assert d < mf["overflow_demand"] <= 3 * n_tiles + 4 * 3 * n_tiles  # some tiles live in one or two chunks (parts of split tiles take their own)
+    assert m["overflow_pool_bytes"] < mf["overflow_pool_bytes"]
+    full.close()
     ref_u8, ref_f32, rc = sc.render(op, threads=8)
     compare(reff, ref_f32, ref8, ref_u8)
     assert rc["hit_evals"] == c0["hit_evals"]
