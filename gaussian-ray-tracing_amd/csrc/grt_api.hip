@@ -428,15 +428,12 @@ static uint64_t faces_hash(uint64_t h, const uint32_t* f, size_t n)
 // (d_ovf_next[0] = chunks this frame asked for, [1] = the largest demand since the host last took one: the pinned word is written
 //  only when the host is not waiting for an earlier value — h_ovf_used == nullptr otherwise — so a peak between two reads is kept)
 __global__ void k_frame_tail(const uint32_t* __restrict__ d_err, uint32_t* __restrict__ h_err, uint32_t* __restrict__ d_ovf_next,
-                             uint32_t* __restrict__ h_ovf_used, const uint32_t* __restrict__ d_qpcount, uint32_t* __restrict__ h_qpcount,
-                             uint32_t fold_demand)
+                             uint32_t* __restrict__ h_ovf_used, const uint32_t* __restrict__ d_qpcount, uint32_t* __restrict__ h_qpcount)
 {
     *h_err = *d_err;
     if (d_qpcount) *h_qpcount = d_qpcount[0]; // how many four-way parts the quad kernel's list holds (a launch that knows it is none skips that kernel)
     if (d_ovf_next) {
-        // (fold_demand = 0: a frame whose tiles had no size classes although its kind has them — a cold frame — asks for a full bag per
-        //  tile: that says nothing about the frames to come and stays out of the readings)
-        const uint32_t peak = fold_demand ? max(d_ovf_next[1], d_ovf_next[0]) : d_ovf_next[1];
+        const uint32_t peak = max(d_ovf_next[1], d_ovf_next[0]);
         d_ovf_next[0] = 0u;
         d_ovf_next[1] = h_ovf_used ? 0u : peak;
         if (h_ovf_used) *h_ovf_used = peak;
@@ -1143,7 +1140,7 @@ static int order_from_costs(grt_ctx* c, const RenderArgs& a, uint32_t n_units, h
         return rcp;
     }
     *used_split = split;
-    c->order_classes = false;
+    c->order_classes = false; // (entries of this order are bare unit numbers)
     return order_units_by_cost(cost_src, c->d_order, n_units, std::max(1u, n_units / (uint32_t)c->opt_heavy_cap_div),
                                (uint32_t)c->opt_heavy_thr_x2, split ? c->d_n_heavy : nullptr, d_zero, s, &c->err);
 }
@@ -1239,7 +1236,6 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             src = c->d_cost;
         }
         c->order_launch = 0;
-        c->order_classes = false; // (made from particle counts: no tile has a size class)
         int rc;
         if (c->opt_cold_estimate >= 2 && c->parts_ok && a.mode == 0 && c->opt_tile_parts4_pct > 0 && !sc->n_faces) {
             // (not on mesh frames: a split tile queues four thin bundles of continuation rays — C4's cold frame 3.30 -> 3.90 ms)
@@ -1249,6 +1245,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
             rc = order_units_with_parts(src, c->d_cost_dil, c->d_order, n_units, cap, 0u, (uint32_t)c->opt_cold_parts_pct,
                                         (uint32_t)c->opt_tile_parts_load_pct, kTileResidentWaves, nullptr, c->d_ord_scratch,
                                         (uint32_t)c->opt_order_multi_min, c->opt_ovf_classes ? 2u /* (particle counts, not cost words) */ : 0u, s, &c->err);
+            c->order_classes = rc == GRT_OK && c->opt_ovf_classes != 0; // (every whole tile "not known": it starts in one chunk)
             if (rc == GRT_OK) {
                 c->order_launch = n_units + cap; a.n_launch = c->order_launch;
                 c->qparts_valid = false;
@@ -1259,6 +1256,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
                 }
             }
         } else {
+            c->order_classes = false;
             rc = order_units_by_cost(src, c->d_order, n_units, 1u, (uint32_t)c->opt_heavy_thr_x2, nullptr, nullptr, s, &c->err);
         }
         if (rc != GRT_OK) return rc;
@@ -1477,13 +1475,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     }
     a.ovf_pool = nullptr; a.ovf_next = nullptr; a.ovf_chunks = 0;
     a.ovf_entries = c->opt_ovf_entries > 0 ? (uint32_t)c->opt_ovf_entries : kTileOvfEntries;
-    { static const char* e0 = getenv("GRT_OVF_BUMP"); a.ovf_bump = e0 ? (uint32_t)atoi(e0) : (c->launch_order_matched ? 0u : 1u); }
-    // does this frame's demand say something about the next ones'?  Not when its kind of frame has size classes (tile kernel, camera rays
-    // without meshes, part-wave policy on) and this one ran without them (a cold frame, no order at all): every tile asked for a full bag
-    {
-        const bool classable = tile_kernel && c->opt_feedback && c->opt_ovf_classes && c->parts_ok && (c->opt_tile_parts2_pct > 0 || c->opt_tile_parts4_pct > 0) && a.n_units == a.n_blocks * 4u;
-        c->ovf_fold = !(classable && !(a.order && c->order_classes));
-    }
+    // (an order whose entries carry size classes: a whole tile without one — no cost word yet — starts in one chunk and moves when it
+    //  outgrows it; an order of bare unit numbers, or none: a full bag, as ever)
+    a.ovf_cls0 = (a.order && c->order_classes) ? 1u : 3u;
     if (tile_kernel) {
         int rco = size_overflow_pool(c, a.n_blocks * 4u, s);
         if (rco != GRT_OK) return rco;
@@ -1604,7 +1598,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     // host word (sizes the pool of the frames to come), and their counter reset for the next frame
     {
         uint32_t* ovf = (rc == GRT_OK) ? a.ovf_next : nullptr;
-        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->ovf_pending ? (uint32_t*)nullptr : c->h_ovf_used, c->d_qpcount, c->h_err + 1, c->ovf_fold ? 1u : 0u);
+        hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(1), 0, s, c->d_err, c->h_err, ovf, c->ovf_pending ? (uint32_t*)nullptr : c->h_ovf_used, c->d_qpcount, c->h_err + 1);
         c->tail_qepoch = c->qlist_epoch;
         if (hipGetLastError() == hipSuccess) {
             tail = true;

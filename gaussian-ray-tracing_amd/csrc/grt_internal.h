@@ -119,7 +119,7 @@ struct RenderArgs {
     uint32_t* ovf_next;      // next free chunk (zeroed before the launch)
     uint32_t ovf_chunks;     // chunks in the pool
     uint32_t ovf_entries;    // per-lane capacity of a bag actually used (<= kTileOvfEntries; smaller only in tests)
-    uint32_t ovf_bump;       // 1: size classes move up by one chunk (the launch order was made from another view's costs), else 0
+    uint32_t ovf_cls0;       // chunks (1 or 3) a whole tile starts in when its order entry carries no size class (grt_render_tile.hip kSub)
     // always-on failure signal: a wave that has to give up on a ray (watchdog, stack guard, two passes without progress)
     // ORs its reason into this device word, whatever the kernel variant; grt_sync / grt_get_counters report it
     uint32_t* err_word;
@@ -271,8 +271,7 @@ struct grt_ctx {
     uint32_t ovf_hist_n = 0;
     bool ovf_stale = false;       // the reading on its way was asked for under another launch geometry
     bool ovf_short = false;       // an allocation of the size wanted failed
-    bool ovf_fold = true;         // this frame's demand counts as a reading (not a cold frame of a kind that has size classes)
-    bool order_classes = false;   // the launch order in d_order carries size classes
+    bool order_classes = false;   // the entries of the launch order in d_order carry size classes (made by order_units_with_parts)
     uint32_t ovf_demand_max = 0;  // ... and the largest of those readings
     std::vector<std::pair<float4*, hipEvent_t>> ovf_old; // pools replaced while frames that may use them were in flight
     uint32_t ovf_units = 0;       // tiles of the launch the pool was last sized for

@@ -58,14 +58,15 @@ constexpr uint32_t kStack = kTileStack; // depth-first overflow stack (only when
 constexpr uint32_t kKeep = 40u; // frontier entries kept in registers by a rebalance (the nearest ones)
 constexpr uint32_t kOvf = kTileOvfEntries; // entries (16 B, global memory) a lane's overflow bag holds at most; the capacity in use is
                                            // a.ovf_entries (<= kOvf; smaller only in tests)
-constexpr uint32_t kSub = kTileOvfSub;     // The pool is handed out in CHUNKS of kSub entries x 64 lanes (32 KiB).  A tile takes three in a
-                                           // row (a full bag per ray) — or two, or ONE, when its bags stayed shallow in the frame before:
-                                           // the cost word's two lowest bits say how full the fullest bag of any of its rays got (0: at most
-                                           // kBagKeep1 entries, 1: at most kBagKeep2, 3: more), the launch order hands the size class
-                                           // back in the part field of a whole tile's entry (grt_bvh.hip).  Of the tiles of the 1 M scene
-                                           // that overflow at all, half never hold more than 16 entries in any bag, 79 % never more than
-                                           // 32, 95 % never more than 48.  A tile that outgrows its chunks prunes and drops as any full bag
-                                           // does (another pass at worst) and takes more in the next frame.
+constexpr uint32_t kSub = kTileOvfSub;     // The pool is handed out in CHUNKS of kSub entries x 64 lanes (32 KiB).  A tile STARTS in one,
+                                           // two or three in a row (three = a full bag per ray) by how deep its bags got in the frame
+                                           // before: the cost word's two lowest bits say how full the fullest bag of any of its rays got
+                                           // (0: at most kBagKeep1 entries, 1: at most kBagKeep2, 3: more), the launch order hands the
+                                           // size class back in the part field of a whole tile's entry (grt_bvh.hip); a tile without a
+                                           // cost word (a cold frame) starts in one.  A tile that outgrows its chunks MOVES to three
+                                           // fresh ones (its rays' entries are copied: a wave-level loop, rare) — no class is ever a limit.
+                                           // Of the tiles of the 1 M scene that overflow at all, half never hold more than 16 entries in
+                                           // any bag, 79 % never more than 32, 95 % never more than 48.
 constexpr uint32_t kBagKeep1 = 20u, kBagKeep2 = 48u; // (a class's bags are pruned 8 entries short of full: at 24 and 56)
 static_assert(kOvf == 3u * kSub && kBagKeep1 < kSub && kBagKeep2 < 2u * kSub, "a full bag is three chunks");
 constexpr int kBisect = 18;          // most bisection steps of a nearest-k selection (4 / 6 at least)
@@ -606,13 +607,15 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         // (QUAD: a ray's four bags TOGETHER hold what one bag of the camera-ray kernel holds.  The capacity is a cut-off, not just room:
         //  a ray whose bag is full stops wanting what lies beyond, the tile's reach shrinks with it and the frontier stays clear of far
         //  entries — with four full-size bags a quadrant of a cluster core went on for 242 steps where the part wave took 164)
-        // (a whole tile whose bags stayed shallow in the frame before — part field 1 or 2 of its order entry — lives in one or two chunks;
-        //  part field 0: a tile without a cost word takes a full bag.  a.ovf_bump = 1: the order was made from the costs of ANOTHER view —
-        //  a camera in motion — and every class moves up by one: what was shallow under the last view may not be under this one)
+        // (a whole tile whose bags stayed shallow in the frame before — part field 1 or 2 of its order entry — starts in one or two chunks;
+        //  part field 0: a tile without a cost word — a cold frame — starts in ONE (a.ovf_cls0; in three when the order's entries are bare
+        //  unit numbers: mesh frames, part waves off).  A tile that outgrows its chunks moves: three fresh
+        //  chunks, what its rays hold is copied over (rare: a wave-level copy of at most 64 entries per ray), and it goes on with a full bag.
+        //  bag_cap: the capacity in use; bit 16: no more moves — the pool had nothing left.  QUAD: a ray's four bags hold a quarter each)
         const uint32_t fld_ = (MODE == 0 && a.order && (ue >> 30) == 0u) ? ((ue >> 28) & 3u) : 3u;
-        const uint32_t cls_ = fld_ ? min(fld_ + a.ovf_bump, 3u) : 3u; // chunks the tile lives in: 1..3 (3: a full bag)
-        const uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : min(a.ovf_entries, cls_ * kSub);
-        const uint32_t prune_room = QUAD ? kPruneRoom / 4u : (cls_ < 3u ? kSub / 4u : kPruneRoom);
+        uint32_t bag_cap = QUAD ? max(a.ovf_entries >> 2, 1u) : min(a.ovf_entries, (fld_ ? fld_ : a.ovf_cls0) * kSub);
+#define GRT_BAG_CAP (bag_cap & 0xFFFFu)
+#define GRT_PRUNE_ROOM (QUAD ? kPruneRoom / 4u : (GRT_BAG_CAP > 2u * kSub ? kPruneRoom : kSub / 4u))
         const uint32_t ready_min = SINGLE ? 1u : a.tile_ready_min; // lanes with a final event before a compositing sweep starts
         // a lone ray meets few boxes per level: it looks much further ahead, so that a step still has 64 boxes to cull
         const float look_ = SINGLE ? a.single_look : a.tile_look, band_ = SINGLE ? a.single_band : a.tile_band;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
                 // any later pass (a lane came back: its cut-off did fall short).  Behind a moving front the arrivals are
                 // ordered, what overflows lies far ahead, and the scans would be wasted (100 k-Gaussian frame: 10-35 % slower).
                 if (!SINGLE && !dfs && bags && ((F <= LO) || npass > 1u)) {
-                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + prune_room >= bag_cap);
+                    const bool pr_ = alive && (chunk < a.ovf_chunks) && (nb + GRT_PRUNE_ROOM >= GRT_BAG_CAP);
                     if (wave_any(pr_)) { // wave-uniform, rare
                         work |= 3u; // (deep bags: below)
                         bag_prune(a.ovf_pool + (size_t)chunk * (kSub * 64u) + lane, pr_, nb, bagmin, lost);
@@ -1287,14 +1290,34 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
                             if (wave_any(drop)) {
                                 if (!SINGLE && chunk == kNoRoot) {
                                     // (as many chunks as the bags may grow to: QUAD — a ray's four bags hold a quarter each — one always)
-                                    const uint32_t nch = (bag_cap + kSub - 1u) / kSub;
+                                    const uint32_t nch = (GRT_BAG_CAP + kSub - 1u) / kSub;
                                     uint32_t ch = 0;
                                     if (lane == 0u) ch = atomicAdd(a.ovf_next, nch);
                                     ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
                                     chunk = (ch + nch <= a.ovf_chunks) ? ch : (kNoRoot - 1u);
                                 }
                                 const uint64_t dk = take ? (KLAST | kCellMask) : (k_first | kCellMask);
-                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < bag_cap) && (dk < lost);
+                                // the tile has outgrown its size class: a full bag elsewhere in the pool, the rays' entries move over
+                                if (MODE == 0 && GRT_BAG_CAP < a.ovf_entries && !(bag_cap >> 16) && chunk < a.ovf_chunks &&
+                                    wave_any(drop && (nb >= GRT_BAG_CAP) && (dk < lost))) {
+                                    uint32_t ch = 0;
+                                    if (lane == 0u) ch = atomicAdd(a.ovf_next, kOvf / kSub);
+                                    ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+                                    if (ch + kOvf / kSub <= a.ovf_chunks) {
+                                        uint32_t nmx = nb;
+                                        for (int off = 32; off > 0; off >>= 1) nmx = max(nmx, (uint32_t)__shfl_xor((int)nmx, off));
+                                        nmx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmx);
+                                        const float4* src_ = a.ovf_pool + (size_t)chunk * (kSub * 64u) + lane;
+                                        float4* dst_ = a.ovf_pool + (size_t)ch * (kSub * 64u) + lane;
+                                        for (uint32_t i = 0; i < nmx; i++)
+                                            if (i < nb) dst_[(size_t)i * 64u] = src_[(size_t)i * 64u];
+                                        chunk = ch;
+                                        bag_cap = a.ovf_entries;
+                                    } else {
+                                        bag_cap |= 0x10000u;
+                                    }
+                                }
+                                const bool to_bag = !SINGLE && drop && (chunk < a.ovf_chunks) && (nb < GRT_BAG_CAP) && (dk < lost);
                                 if (to_bag) {
                                     const float d_o = take ? PL_OTHER(cell) : other, d_a = take ? PL_ALPHA(cell) : alpha;
                                     a.ovf_pool[((size_t)chunk * kSub + nb) * 64u + lane] =
@@ -1522,6 +1545,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
 }
 
 #undef GRT_IN_PART
+#undef GRT_BAG_CAP
+#undef GRT_PRUNE_ROOM
 #undef GRT_TILE_CHECK_FRONT
 #undef KS
 #undef KLAST
