@@ -542,14 +542,14 @@ static void free_meshes(grt_ctx* c)
 }
 
 // everything a frame slot owns (a view has nothing else)
-static void reap_old_pools(grt_ctx* c, bool force);
+static void reap_old_pools(grt_ctx* c, bool force, hipStream_t s);
 static void free_slot_state(grt_ctx* c)
 {
     (void)hipFree(c->d_erec); (void)hipFree(c->d_erec_wide);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch); (void)hipFree(c->d_qparts); (void)hipFree(c->d_qpcount);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
-    reap_old_pools(c, true);
+    reap_old_pools(c, true, nullptr);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
     if (c->h_ovf_used) (void)hipHostFree(c->h_ovf_used);
@@ -628,7 +628,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
-    else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; }
+    else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; c->ovf_sized = false; }
     else if (option == GRT_OPT_OVF_ENTRIES) {
         if (value < 0 || value > (int)kTileOvfEntries) { c->err = "GRT_OPT_OVF_ENTRIES must be 0.." + std::to_string(kTileOvfEntries); return GRT_ERR_INVALID; }
         c->opt_ovf_entries = value;
@@ -1283,7 +1283,7 @@ static int prepare_feedback(grt_ctx* c, RenderArgs& a, hipStream_t s, uint32_t n
 // largest demand ever seen, in whole 96-entry bags (1.3 GB at 1080p).  Now the pool follows the DEMAND both ways: every frame's chunk
 // counter is read back behind it (pinned word, no sync; the device keeps the peak between two reads) and the last eight readings are
 // kept.  The pool is 1.25 x their MEDIAN + 64 (one cold frame — a camera cut: no size classes, every tile asks for more — does not move
-// it); it GROWS when the median comes within 10 % of it and SHRINKS when it is more than 1.5 x what the LARGEST of the eight would ask
+// it); it GROWS when the median comes within 10 % of it and SHRINKS when it is more than 1.2 x what the LARGEST of the eight would ask
 // for (so a spike only delays a shrink, and a demand that wanders does not re-make the pool every frame).  A re-size does not wait for
 // the device: the new pool is allocated beside the old one, which is freed once the frames that may use it have drained (hipFree
 // synchronises: it is called when nothing of this scene is in flight, or at the latest when a third pool would pile up).  The first
@@ -1303,13 +1303,15 @@ static void overflow_demand_stats(const grt_ctx* c, uint32_t* median, uint32_t* 
 }
 
 // old pools whose last users may still run: freed when their event has passed and no frame of the scene is in flight (force: now)
-static void reap_old_pools(grt_ctx* c, bool force)
+static void reap_old_pools(grt_ctx* c, bool force, hipStream_t s = nullptr)
 {
     if (c->ovf_old.empty()) return;
-    if (!force && c->ovf_old.size() < 2u && sibling_frames_in_flight(c)) return;
+    // (hipFree waits for the whole device: not while frames of this slot are queued on its stream — a loop that queues its frames
+    //  without waiting would drain — nor while a sibling slot has frames in flight; a third pool piling up is freed regardless)
+    if (!force && c->ovf_old.size() < 3u && (sibling_frames_in_flight(c) || (s && hipStreamQuery(s) != hipSuccess))) { (void)hipGetLastError(); return; }
     for (size_t i = 0; i < c->ovf_old.size();) {
         auto& o = c->ovf_old[i];
-        if (force || c->ovf_old.size() >= 2u || hipEventQuery(o.second) == hipSuccess) {
+        if (force || c->ovf_old.size() >= 3u || hipEventQuery(o.second) == hipSuccess) {
             if (hipEventQuery(o.second) != hipSuccess) (void)hipEventSynchronize(o.second);
             (void)hipFree(o.first);
             (void)hipEventDestroy(o.second);
@@ -1323,8 +1325,8 @@ static void reap_old_pools(grt_ctx* c, bool force)
 static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
 {
     grt_ctx* sc = scene_of(c);
-    reap_old_pools(c, false);
-    if (c->ovf_units != n_tiles) { c->ovf_hist_n = 0; c->ovf_demand = 0; c->ovf_short = false; c->ovf_units = n_tiles; c->ovf_stale = c->ovf_pending; } // another launch geometry: start over
+    reap_old_pools(c, false, s);
+    if (c->ovf_units != n_tiles) { c->ovf_hist_n = 0; c->ovf_demand = 0; c->ovf_short = false; c->ovf_sized = false; c->ovf_units = n_tiles; c->ovf_stale = c->ovf_pending; } // another launch geometry: start over
     if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
         if (!c->ovf_stale) { // (a reading asked for under the geometry before says nothing about this one)
             if (*c->h_ovf_used != 0u) { // (0: nothing but frames that do not count since the last reading)
@@ -1355,10 +1357,19 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
         } else {
                 want = std::min(most, d + d / 4u + 64u);
             const uint32_t keep = std::min(most, dmax + dmax / 4u + 64u); // what the largest recent demand would ask for
-            const bool grow = c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short;
-            const bool shrink = c->ovf_chunks > keep + keep / 2u;
+            // WHEN: a re-size costs milliseconds of host time (hipMalloc of half a gigabyte: ~5 ms), during which a loop that queues its
+            // frames without waiting runs dry.  So the pool is re-made only at a frame the application waited for (nothing queued on
+            // the frame's stream) — except the first sizing from a known demand (the pool still holds three chunks for every tile: it
+            // happens in the first frames of a view) and a pool that ran DRY (the last frame asked for more than there is)
+            const bool idle = hipStreamQuery(s) == hipSuccess;
+            (void)hipGetLastError();
+            const uint32_t last = c->ovf_hist_n ? c->ovf_hist[(c->ovf_hist_n - 1u) % 8u] : d;
+            const bool first = !c->ovf_sized;
+            const bool grow = c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short && (idle || first || last > c->ovf_chunks);
+            const bool shrink = c->ovf_chunks > keep + keep / 5u && (idle || first);
             resize = grow || shrink;
             if (shrink && !grow) want = keep;
+            if (resize) c->ovf_sized = true;
         }
     }
     if (resize) {
@@ -1372,7 +1383,6 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
                 (void)hipDeviceSynchronize();
                 (void)hipFree(c->d_ovf);
             }
-            reap_old_pools(c, false);
         }
         c->d_ovf = nullptr;
         c->ovf_chunks = 0;
@@ -1381,7 +1391,7 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
             c->ovf_short = true; // (the memory is not there: growing is not tried again for this launch geometry)
             (void)hipGetLastError(); // out of memory is not an error of the frame: a smaller pool, or none
             c->d_ovf = nullptr;
-            reap_old_pools(c, true); // (what waits to be freed may be what is missing)
+            reap_old_pools(c, true, nullptr); // (what waits to be freed may be what is missing)
             if (c->opt_ovf_chunks > 0) break;
         }
     }
@@ -1477,7 +1487,9 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.ovf_entries = c->opt_ovf_entries > 0 ? (uint32_t)c->opt_ovf_entries : kTileOvfEntries;
     // (an order whose entries carry size classes: a whole tile without one — no cost word yet — starts in one chunk and moves when it
     //  outgrows it; an order of bare unit numbers, or none: a full bag, as ever)
-    a.ovf_cls0 = (a.order && c->order_classes) ? 1u : 3u;
+    //  (a scene whose tiles are nearly all deep — the needle scene: 2.8 chunks asked for per tile of the launch — gains nothing from the
+    //   small start and pays a move per tile on every cold frame, 16.5 -> 18.5 ms: there a tile without a class starts with a full bag too)
+    a.ovf_cls0 = (a.order && c->order_classes && !(c->ovf_units == a.n_blocks * 4u && (uint64_t)c->ovf_demand * 2u > (uint64_t)a.n_blocks * 4u * 3u)) ? 1u : 3u;
     if (tile_kernel) {
         int rco = size_overflow_pool(c, a.n_blocks * 4u, s);
         if (rco != GRT_OK) return rco;
