@@ -412,9 +412,9 @@ def main():
         t.check()  # raises when a wave gave up on live rays anywhere in the run (sticky device error word)
     mem = [t.memory_info() for t in trs]
     # (the overflow pool follows the median demand of the last eight frames it has READ BACK, and a loop that queues its frames without
-    #  waiting reads few: ten more synchronised standing frames on slot 0, outside every timed region, show what the slot settles at)
+    #  waiting reads few: sixteen more synchronised standing frames on slot 0, outside every timed region, show what the slot settles at)
     if extra:  # (not in the runs the profiles are taken from: their last K dispatches are the timed loop)
-        for _ in range(10):
+        for _ in range(16):
             one_frame()
             tr.sync()
     mem_settled = tr.memory_info()
@@ -474,7 +474,7 @@ def main():
                                                "note": "one scene shared by all frame slots (views); the pool of window-overflow bags (32 KiB chunks, "
                                                        "one to three per tile that overflows) follows the median demand of the last eight frames READ BACK, "
                                                        "both ways; frame_slots = as the legs of this run left them (cold frames, a moving camera, loops that "
-                                                       "queue frames without waiting), frame_slot_0_settled = slot 0 after ten more synchronised standing frames"},
+                                                       "queue frames without waiting), frame_slot_0_settled = slot 0 after sixteen more synchronised standing frames"},
                        "value_sync": None if value_sync is None else round(value_sync, 3),
                        "value_pipelined": None if value_pipe is None else round(value_pipe, 3),
                        "pipelined_frames_in_flight": D if D > 1 else (D_other or None),

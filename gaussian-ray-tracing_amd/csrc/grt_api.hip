@@ -1307,8 +1307,10 @@ static void reap_old_pools(grt_ctx* c, bool force, hipStream_t s = nullptr)
 {
     if (c->ovf_old.empty()) return;
     // (hipFree waits for the whole device: not while frames of this slot are queued on its stream — a loop that queues its frames
-    //  without waiting would drain — nor while a sibling slot has frames in flight; a third pool piling up is freed regardless)
-    if (!force && c->ovf_old.size() < 3u && (sibling_frames_in_flight(c) || (s && hipStreamQuery(s) != hipSuccess))) { (void)hipGetLastError(); return; }
+    //  without waiting would drain, and the head of such a loop would pay for the free — nor while a sibling slot has frames in flight; a
+    //  third pool piling up is freed regardless)
+    (void)s;
+    if (!force && c->ovf_old.size() < 3u && (sibling_frames_in_flight(c) || c->ovf_idle_run < 2u)) return;
     for (size_t i = 0; i < c->ovf_old.size();) {
         auto& o = c->ovf_old[i];
         if (force || c->ovf_old.size() >= 3u || hipEventQuery(o.second) == hipSuccess) {
@@ -1325,6 +1327,10 @@ static void reap_old_pools(grt_ctx* c, bool force, hipStream_t s = nullptr)
 static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
 {
     grt_ctx* sc = scene_of(c);
+    // (does the application wait for its frames?  Two frames in a row that find their stream idle: the first frame behind a synchronisation
+    //  point may be the head of a loop that does not wait)
+    c->ovf_idle_run = (hipStreamQuery(s) == hipSuccess) ? std::min(c->ovf_idle_run + 1u, 8u) : 0u;
+    (void)hipGetLastError();
     reap_old_pools(c, false, s);
     if (c->ovf_units != n_tiles) { c->ovf_hist_n = 0; c->ovf_demand = 0; c->ovf_short = false; c->ovf_sized = false; c->ovf_units = n_tiles; c->ovf_stale = c->ovf_pending; } // another launch geometry: start over
     if (c->ovf_pending && hipEventQuery(c->ev_ovf) == hipSuccess) {
@@ -1361,8 +1367,7 @@ static int size_overflow_pool(grt_ctx* c, uint32_t n_tiles, hipStream_t s)
             // frames without waiting runs dry.  So the pool is re-made only at a frame the application waited for (nothing queued on
             // the frame's stream) — except the first sizing from a known demand (the pool still holds three chunks for every tile: it
             // happens in the first frames of a view) and a pool that ran DRY (the last frame asked for more than there is)
-            const bool idle = hipStreamQuery(s) == hipSuccess;
-            (void)hipGetLastError();
+            const bool idle = c->ovf_idle_run >= 2u;
             const uint32_t last = c->ovf_hist_n ? c->ovf_hist[(c->ovf_hist_n - 1u) % 8u] : d;
             const bool first = !c->ovf_sized;
             const bool grow = c->ovf_chunks < std::min(most, d + d / 10u) && !c->ovf_short && (idle || first || last > c->ovf_chunks);

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(1024) void k_cost_order_parts(const uint32_t* cost,
                 const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
                 const uint32_t pos = atomicAdd(&cursor[b], parts);
                 // (a whole tile's part field carries its bags' size class: the chunks of the pool it takes, 0 = not known)
-                if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : rv[k]) << 28);
+                if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : cv[k]) << 28);
                 else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
             }
             __syncthreads();
@@ -899,13 +899,13 @@ __global__ __launch_bounds__(1024) void k_ord_d(const uint32_t* cost, const uint
     for (uint32_t base = lo; base < hi; base += 1024u) { // (1024 units at a time, a barrier between them: the tiles of a class stay in screen order)
         const uint32_t i = base + tid;
         if (i < hi) {
-            const uint32_t rw = raw[i];
-            const uint32_t r = cost_eff(rw), b = 127u - cost_class(cost_eff(cost[i]));
+            const uint32_t rw = raw[i], cw = cost[i];
+            const uint32_t r = cost_eff(rw), b = 127u - cost_class(cost_eff(cw));
             const bool two_way = t2 != 0xFFFFFFFFu;
             const uint32_t code = (r > t4) ? (ok4[b] ? 2u : ((two_way && ok2[b]) ? 1u : 0u)) : ((r > t2 && ok2[b]) ? 1u : 0u);
             const uint32_t parts = code == 2u ? 4u : (code == 1u ? 2u : 1u);
             const uint32_t pos = atomicAdd(&cursor[b], parts);
-            if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : rw) << 28); // (the bags' size class: k_cost_order_parts)
+            if (code == 0u) order[pos] = i | (bag_class(bag_classes, bag_classes == 2u ? 0u : cw) << 28); // (the bags' size class: k_cost_order_parts)
             else for (uint32_t q = 0; q < parts; q++) order[pos + q] = i | (q << 28) | (code << 30);
         }
         __syncthreads();
@@ -997,15 +997,17 @@ __global__ void k_cost_dilate(const uint32_t* __restrict__ cost, uint32_t* __res
     const uint32_t b = u >> 2, q = u & 3u;
     const int tx = (int)((b % nbx) * 2u + (q & 1u)), ty = (int)((b / nbx) * 2u + (q >> 1));
     const int ntx = (int)nbx * 2, nty = (int)nby * 2;
-    uint32_t m = 0;
+    uint32_t m = 0, deep = 0; // (deep: the two lowest bits of the tile kernel's cost words — how full the bags got, 0 / 1 / 3 — dilate too:
+                              //  the size class a tile starts with under a moving camera is its neighbourhood's deepest)
     for (int dy = -radius; dy <= radius; dy++)
         for (int dx = -radius; dx <= radius; dx++) {
             const int x = tx + dx, y = ty + dy;
             if (x < 0 || y < 0 || x >= ntx || y >= nty) continue;
             const uint32_t v = cost[(((uint32_t)y >> 1) * nbx + ((uint32_t)x >> 1)) * 4u + (((uint32_t)y & 1u) << 1) + ((uint32_t)x & 1u)];
             m = max(m, cost_eff(v));
+            deep = max(deep, v & 3u);
         }
-    out[u] = m;
+    out[u] = m >= 4u ? ((m & ~3u) | deep) : m;
 }
 
 int dilate_unit_costs(const uint32_t* d_cost, uint32_t* d_out, uint32_t nbx, uint32_t nby, int radius, hipStream_t stream,

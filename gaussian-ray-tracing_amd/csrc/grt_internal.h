@@ -271,6 +271,7 @@ struct grt_ctx {
     uint32_t ovf_hist_n = 0;
     bool ovf_stale = false;       // the reading on its way was asked for under another launch geometry
     bool ovf_short = false;       // an allocation of the size wanted failed
+    uint32_t ovf_idle_run = 0;    // consecutive frames that found their stream idle (the application waits for its frames)
     bool ovf_sized = false;       // the pool in hand was made from a known demand (not the three chunks per tile of a first frame)
     bool order_classes = false;   // the entries of the launch order in d_order carry size classes (made by order_units_with_parts)
     uint32_t ovf_demand_max = 0;  // ... and the largest of those readings
