@@ -170,6 +170,8 @@ constexpr uint32_t kCostStackBit = 0x40000000u, kCostStallBit = 0x20000000u; // 
 // that back to the whole tile's (cost_eff: x 9/8 for halves, x 10/8 for quarters — measured: a quarter of the heaviest tile
 // of the 1 M scene takes 0.79 of the whole tile's time, a half all of it), or a tile would be split on every other frame only.
 // (A larger factor inflates the split tiles' costs frame over frame until their parts no longer fit the launch.)
+// A WHOLE tile's entry (code 0) uses the part field for the size class of its overflow bags: the chunks of the pool it starts in (1, 2,
+// 3; 0 = no cost word yet), from the two lowest bits of its cost word (grt_render_tile.hip kBagKeep1 / kBagKeep2, grt_bvh.hip bag_class).
 constexpr uint32_t kOrderUnitMask = 0x0FFFFFFFu, kOrderPad = 0xFFFFFFFFu;
 // code 3 = a four-way part that runs on the QUAD kernel (grt_render_tile.hip MODE 3): k_quad_list (grt_bvh.hip) re-codes the first
 // kQuadListCap four-way entries of an order and lists them for that kernel, whose grid is the list's capacity; what does not fit
