@@ -210,9 +210,11 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            rank's share of a frame), with a four-way threshold scaled down to half for launches of one tile per resident
                                            wave and fewer; 2: whatever the size (testing); > 2: and at most that many parts (testing); 0: part
                                            waves of the camera-ray kernel with 16 of 64 lanes in use (round 4).  Same pixels either way */,
-       GRT_OPT_OVF_CLASSES = 34         /* 1 (default): a tile takes one, two or three 32-entry chunks of the overflow pool by how deep its
-                                           bags got in the frame before (the frame slot's memory: 1.30 -> 0.64 GB on the 1080p benchmark
-                                           frame); 0: three for every tile that overflows (round 4).  Same pixels either way */ };
+       GRT_OPT_OVF_CLASSES = 34         /* 1 (default): a tile STARTS in one, two or three 32-entry chunks of the overflow pool by how deep
+                                           its bags got in the frame before (one when nothing is known of it) and moves to three fresh
+                                           ones when it outgrows them (the frame slot's memory: 1.30 -> 0.63 GB on the 1080p benchmark
+                                           frame under a standing camera); 0: three for every tile that overflows (round 4).  Same
+                                           pixels either way */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
