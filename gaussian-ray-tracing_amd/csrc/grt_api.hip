@@ -626,6 +626,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
+    else if (option == GRT_OPT_BVH_ROTATIONS) { NOT_A_VIEW(c, "GRT_OPT_BVH_ROTATIONS"); c->opt_bvh_rotations = value < 0 ? -1 : (value > 8 ? 8 : value); }
     else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
     else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
     else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; c->ovf_sized = false; }
@@ -800,7 +801,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
     }
     if (rc == GRT_OK)
         rc = build_lbvh(d_owner ? d_plo : d_lo, d_owner ? d_phi : d_hi, d_owner ? n_pieces : n, (uint32_t)c->opt_leaf_max, true, false,
-                        c->opt_size_classes, &c->gbvh, c->stream, &c->err, d_owner != nullptr);
+                        c->opt_size_classes, &c->gbvh, c->stream, &c->err, d_owner != nullptr, c->opt_bvh_rotations);
     if (rc == GRT_OK && c->gbvh.n_prims) {
         const uint32_t m = c->gbvh.n_prims;
         if (c->cap_rec < m) {
@@ -988,6 +989,39 @@ int grt_get_bvh_info(const grt_ctx* c, grt_bvh_info* o)
     o->build_ms = sc->build_ms;
     o->mesh_update_ms = sc->mesh_update_ms;
     for (int k = 0; k < 3; k++) { o->scene_lo[k] = sc->gbvh.lo[k]; o->scene_hi[k] = sc->gbvh.hi[k]; }
+    return GRT_OK;
+}
+
+// (testing) The depth of the Gaussian LBVH as a traversal meets it, WALKED on the host over a copy of the binary node records — independent
+// of the level bookkeeping of the build, whose root level grt_get_bvh_info reports as `height` and the kernels size their stacks by.
+int grt_debug_bvh_depth(grt_ctx* c, uint32_t* out_depth)
+{
+    if (!c || !out_depth) return GRT_ERR_INVALID;
+    grt_ctx* sc = scene_of(c);
+    *out_depth = 0;
+    const uint32_t m = sc->gbvh.n_prims;
+    if (m == 0 || (sc->gbvh.root_ref & kLeafBit) || !sc->gbvh.nodes) return GRT_OK;
+    (void)hipSetDevice(sc->device);
+    std::vector<float4> h((size_t)(m - 1) * 4);
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(h.data(), sc->gbvh.nodes, h.size() * sizeof(float4), hipMemcpyDeviceToHost) != hipSuccess) {
+        c->err = "grt_debug_bvh_depth: copy of the node records failed";
+        return GRT_ERR_HIP;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> stack; // (node, depth counted in internal nodes)
+    stack.emplace_back(0u, 1u);
+    uint64_t visited = 0;
+    while (!stack.empty()) {
+        const auto [i, d] = stack.back();
+        stack.pop_back();
+        if (i >= m - 1 || ++visited > (uint64_t)m) { c->err = "grt_debug_bvh_depth: the node records are not a tree"; return GRT_ERR_LIMIT; }
+        *out_depth = std::max(*out_depth, d);
+        uint32_t ch[2];
+        memcpy(&ch[0], &h[(size_t)i * 4 + 3].x, 4);
+        memcpy(&ch[1], &h[(size_t)i * 4 + 3].y, 4);
+        for (int k = 0; k < 2; k++)
+            if (!(ch[k] & kLeafBit)) stack.emplace_back(ch[k], d + 1u);
+    }
     return GRT_OK;
 }
 

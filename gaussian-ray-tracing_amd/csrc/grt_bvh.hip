@@ -503,6 +503,22 @@ __global__ void k_rotate_pass(float4* __restrict__ nodes, const uint32_t* __rest
     if (n_done) atomicAdd(n_done, 1u);
 }
 
+// Levels of a tree whose topology a rotation sweep has changed: level = 1 + the larger of the children's (a leaf reference counts 0), found
+// the way the refit found them — a launch per level, a node is numbered in pass p only from children numbered in passes < p, so every
+// hand-off crosses a kernel boundary.  The root's level is the tree's HEIGHT, which sizes the traversal stacks (the sweep pushes
+// a sibling one level down, so the height the refit measured before it is no bound any more), and levels numbered for the topology as it
+// stands are what makes a further sweep sound (two nodes of one pass are then never parent and child).
+__global__ void k_level_pass(const float4* __restrict__ nodes, uint32_t* __restrict__ level, int m, uint32_t pass)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m - 1 || level[i] != 0) return;
+    const float4 q3 = nodes[(size_t)i * 4 + 3];
+    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+    if (!(c0 & kLeafBit)) { const uint32_t lv = level[c0]; if (lv == 0 || lv >= pass) return; }
+    if (!(c1 & kLeafBit)) { const uint32_t lv = level[c1]; if (lv == 0 || lv >= pass) return; }
+    level[i] = pass;
+}
+
 // ---- launch order of the scheduling units: heaviest first, by cost CLASS ----
 // A class keeps the leading 3 bits of the cost (124 classes); inside a class the units stay in (approximately) screen
 // order, so neighbours that share BVH nodes are launched together and — through the XCD-aware rank map of the kernels —
@@ -1249,7 +1265,7 @@ fail:
 }
 
 int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
-               int size_classes, DevBvh* out, hipStream_t stream, std::string* err, bool widen_area_only)
+               int size_classes, DevBvh* out, hipStream_t stream, std::string* err, bool widen_area_only, int rotation_sweeps)
 {
     uint2* d_range = nullptr;
     uint32_t* d_bounds = nullptr;
@@ -1379,16 +1395,36 @@ int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t l
     HIPCHK(hipMalloc(&out->wnodes, sizeof(float4) * 8 * (size_t)(m - 1) + 256));
     if (leaf_max > 1)
         hipLaunchKernelGGL(k_collapse, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_range, (int)m, leaf_max);
-    // ONE bottom-up sweep of rotations, for the Gaussian BVH of a scene with pieces (widen_area_only: needles and sheets — where large
-    // and small boxes overlap and the sweep pays: C3a 14.56 -> 13.77 ms; compact scenes: C3 / C2 flat, C5 -1 %, two of the three dense-core
-    // cameras +3 / +13 %: left alone).  One sweep only: a second one would need the levels re-derived (after a swap a node and its new child
-    // can carry the same stale level, and two threads of one pass then rewrite one record: seen as changed pixels).  GRT_BVH_ROTATIONS=0 / 1
-    // overrides the choice (tuning aid).
+    // Bottom-up sweeps of rotations, for the Gaussian BVH of a scene with pieces (widen_area_only: needles and sheets — where large
+    // and small boxes overlap and a sweep pays: C3a 14.56 -> 13.77 ms; compact scenes: C3 / C2 flat, C5 -1 %, two of the three dense-core
+    // cameras +3 / +13 %: left alone).  GRT_OPT_BVH_ROTATIONS (rotation_sweeps): -1 = that choice with one sweep, 0 = none, n = n sweeps on
+    // any tree.  Behind EVERY sweep the levels are numbered afresh for the topology as it stands (k_level_pass) and the height is the
+    // root's new level: a swap pushes the sibling one level down, so the refit's height is no bound for the rotated tree (it sizes the
+    // per-lane kernel's LDS stack and decides tile_stack_fits / the wave kernel's depth test), and a sweep by stale levels lets two
+    // threads of one pass rewrite one record (round 5 saw that as changed pixels and shipped a single sweep on the old levels).
     {
-        static const char* env = getenv("GRT_BVH_ROTATIONS");
-        const bool rotate = want_quad && (env ? atoi(env) != 0 : widen_area_only);
-        for (uint32_t pass = 2; rotate && pass <= out->height; pass++)
-            hipLaunchKernelGGL(k_rotate_pass, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_level, (int)m, pass, (uint32_t*)nullptr);
+        const int sweeps = want_quad ? (rotation_sweeps < 0 ? (widen_area_only ? 1 : 0) : std::min(rotation_sweeps, 8)) : 0;
+        for (int sw = 0; sw < sweeps; sw++) {
+            for (uint32_t pass = 2; pass <= out->height; pass++)
+                hipLaunchKernelGGL(k_rotate_pass, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_level, (int)m, pass, (uint32_t*)nullptr);
+            HIPCHK(hipMemsetAsync(d_level, 0, sizeof(uint32_t) * (m - 1), stream));
+            uint32_t pass = 0, root_level = 0;
+            const uint32_t h_old = out->height;
+            while (root_level == 0) {
+                pass++;
+                if (pass > 4096) {
+                    if (err) *err = "build_lbvh: levels of the rotated tree did not converge";
+                    goto fail_limit;
+                }
+                hipLaunchKernelGGL(k_level_pass, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, d_level, (int)m, pass);
+                // a sweep changes the height by little: look first where the old height says the root may be done, then every 4 passes
+                if (pass + 2 >= h_old && ((pass + 2 - h_old) & 3u) == 0u) {
+                    HIPCHK(hipMemcpyAsync(&root_level, d_level, 4, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(hipStreamSynchronize(stream));
+                }
+            }
+            out->height = root_level;
+        }
     }
     hipLaunchKernelGGL(k_widen, dim3((m - 1 + B - 1) / B), dim3(B), 0, stream, out->nodes, (int)m, out->wnodes);
     if (want_quad) {

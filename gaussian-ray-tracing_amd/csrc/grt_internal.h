@@ -52,8 +52,10 @@ struct DevBvh {
 // keep_levels: keep the per-node refit order so that refit_lbvh can re-fit the boxes of the SAME hierarchy later.
 // size_classes: Gaussian BVH only (GRT_OPT_SIZE_CLASSES of the context that builds).
 int build_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, uint32_t leaf_max, bool want_quad, bool keep_levels,
-               int size_classes, DevBvh* out, hipStream_t stream, std::string* err, bool widen_area_only = false);
-// (widen_area_only: the 8-wide records open the largest box first throughout — trees with pieces; grt_bvh.hip: k_qwiden)
+               int size_classes, DevBvh* out, hipStream_t stream, std::string* err, bool widen_area_only = false,
+               int rotation_sweeps = -1);
+// (widen_area_only: the 8-wide records open the largest box first throughout — trees with pieces; grt_bvh.hip: k_qwiden.
+//  rotation_sweeps: GRT_OPT_BVH_ROTATIONS of the context that builds; DevBvh::height is the height of the tree as traversed, rotations included)
 // Re-fit every reachable node's boxes to new primitive boxes (same primitives, same order, same hierarchy): what a
 // gizmo drag needs (reference: full GAS + IAS rebuild per frame, src/GaussianTracer.cpp:711-794).
 int refit_lbvh(const float4* d_lo, const float4* d_hi, uint32_t n_in, DevBvh* bvh, hipStream_t stream, std::string* err);
@@ -254,6 +256,7 @@ struct grt_ctx {
     int opt_swizzle = 2;
     int opt_tile_ready = 24, opt_tile_band = 64, opt_tile_look = 64, opt_tile_reserve = -1 /* auto: 16, trees with pieces 24 */, opt_tile_prio = 0; // band / look in 1/1024
     int opt_size_classes = 1;
+    int opt_bvh_rotations = -1; // GRT_OPT_BVH_ROTATIONS
     int opt_band_abs = 512;       // GRT_OPT_TILE_BAND_ABS: that floor in 1/64 of the geometric-mean proxy diagonal
     float gm_diag = 0.f;          // geometric mean of the proxies' box diagonals (grt_build_bvh)
     int opt_split = 8;            // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off)

@@ -67,12 +67,13 @@ OPT_STATIC_SHARP = 31
 OPT_COLD_PARTS_PCT = 32
 OPT_QUAD_PARTS = 33
 OPT_OVF_CLASSES = 34
+OPT_BVH_ROTATIONS = 35
 ERR_LIMIT = -5
 KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERNEL_TILE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
     "grt_create", "grt_create_view", "grt_get_memory_info", "grt_destroy", "grt_last_error", "grt_set_option", "grt_upload_gaussians", "grt_build_bvh",
-    "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_render", "grt_render_tiles", "grt_assemble_tiles", "grt_render_rays", "grt_sync",
+    "grt_set_meshes", "grt_update_meshes", "grt_get_bvh_info", "grt_debug_bvh_depth", "grt_render", "grt_render_tiles", "grt_assemble_tiles", "grt_render_rays", "grt_sync",
     "grt_get_counters", "grt_last_kernel_ms", "grt_host_activate", "grt_host_uvw_frame", "grt_host_synth_scene",
     "grt_host_ply_count", "grt_host_ply_read", "grt_host_ply_write", "grt_host_last_error",
     "grt_host_primitive_counts", "grt_host_primitive_fill", "grt_host_obj_count", "grt_host_obj_read", "grt_host_obj_write",
@@ -110,6 +111,7 @@ def lib():
         L.grt_set_meshes.argtypes = [vp, C.POINTER(Mesh), u32]
         L.grt_update_meshes.argtypes = [vp, C.POINTER(Mesh), u32]
         L.grt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
+        L.grt_debug_bvh_depth.argtypes = [vp, C.POINTER(u32)]
         L.grt_render.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, vp]
         L.grt_render_tiles.argtypes = [vp, C.POINTER(Params), vp, vp, u32, u32, u32, u32, u32, vp]
         L.grt_assemble_tiles.argtypes = [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]
@@ -352,6 +354,12 @@ class Tracer:
         o = BvhInfo()
         self._check(lib().grt_get_bvh_info(self._h, C.byref(o)))
         return {n: (list(getattr(o, n)) if n.startswith("scene") else getattr(o, n)) for n, _ in o._fields_}
+
+    def bvh_depth_walked(self):
+        """(testing) depth of the Gaussian LBVH walked on the host; must be <= bvh_info()['height']."""
+        d = C.c_uint32(0)
+        self._check(lib().grt_debug_bvh_depth(self._h, C.byref(d)))
+        return int(d.value)
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)

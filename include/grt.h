@@ -214,7 +214,12 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            its bags got in the frame before (one when nothing is known of it) and moves to three fresh
                                            ones when it outgrows them (the frame slot's memory: 1.30 -> 0.63 GB on the 1080p benchmark
                                            frame under a standing camera); 0: three for every tile that overflows (round 4).  Same
-                                           pixels either way */ };
+                                           pixels either way */,
+       GRT_OPT_BVH_ROTATIONS = 35       /* applies to the next build of the Gaussian BVH (refused on a view): bottom-up sweeps of tree rotations
+                                           behind the LBVH build — what the reference asks OptiX for with PREFER_FAST_TRACE,
+                                           src/GaussianTracer.cpp:360.  -1 (default): one sweep for trees that hold pieces of split proxies,
+                                           none otherwise; 0: none; n (<= 8): n sweeps on any tree.  Levels and the reported height
+                                           (grt_bvh_info) are re-derived behind every sweep.  Culling structure only: same pixels */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
@@ -237,6 +242,9 @@ GRT_API int grt_set_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_mesh
 GRT_API int grt_update_meshes(grt_ctx* ctx, const grt_mesh* meshes, uint32_t n_meshes);
 GRT_API int grt_get_bvh_info(const grt_ctx* ctx, grt_bvh_info* out);
 GRT_API int grt_get_memory_info(const grt_ctx* ctx, grt_memory_info* out);
+/* (testing) depth of the Gaussian LBVH walked on the host over a copy of its node records, in levels of internal nodes: must not
+ * exceed grt_bvh_info::height, which sizes the kernels' traversal stacks (synchronises the device; ~0.1 s per million nodes). */
+GRT_API int grt_debug_bvh_depth(grt_ctx* ctx, uint32_t* out_depth);
 
 /* ---- render (all asynchronous on `stream`, a hipStream_t; NULL = the context's own stream) ----
  * d_rgb8 : device uchar3 frame, row-major y*width+x (shaders/tracer.cuh:484-496), may be NULL

@@ -428,6 +428,9 @@ struct grto_scene {
     float* mv; float* mn; uint32_t nv;
     uint32_t* mf; uint32_t nf;
     bvh_t mbvh;
+    /* brute-force proxy mode (grto_scene_set_proxy_triangles): world-space vertices of every particle's instanced
+     * icosahedron [n][12][3], by ORIGINAL particle id, and the 20 faces' indices — supplied by the caller */
+    float* ptv; uint32_t pti[60]; int tri_mode;
 };
 
 typedef struct { const float* lo; const float* hi; float* cen; uint32_t* prim; node_t* nodes; uint32_t n_nodes; } build_t;
@@ -581,9 +584,29 @@ void grto_scene_set_mesh(grto_scene* s, const float* verts, const float* normals
     free(lo); free(hi);
 }
 
+/* Decision (v) of SURVEY 8(c) replaces the ray / triangle tests OptiX runs against the instanced 20-triangle icosahedron
+ * (src/geometry/Icosahedron.h:13-37; instance transform T * (R * S), src/GaussianTracer.cpp:304-311; one GAS, one instance per
+ * particle, :401-420) by ten slab tests in Gaussian space.  This mode puts the triangles back, for CHECKING that decision on whole
+ * frames: the caller hands over the instanced vertices — the tests take them from oracle/_ref (ref_instance_vertex x
+ * ref_icosahedron: the reference's own glm chain and mesh, compiled from its sources) — and every proxy test intersects the 20
+ * triangles (Moeller-Trumbore in double precision, no culling: tracer.cuh:306) instead of the slabs; everything behind the
+ * intersection (interval, k-buffer, response, integration) is unchanged.  verts == NULL switches back. */
+void grto_scene_set_proxy_triangles(grto_scene* s, const float* verts, const uint32_t idx[60])
+{
+    free(s->ptv);
+    s->ptv = NULL;
+    s->tri_mode = 0;
+    if (!verts) return;
+    s->ptv = (float*)malloc(sizeof(float) * 36 * (s->n ? s->n : 1));
+    memcpy(s->ptv, verts, sizeof(float) * 36 * s->n);
+    memcpy(s->pti, idx, sizeof(uint32_t) * 60);
+    s->tri_mode = 1;
+}
+
 void grto_scene_destroy(grto_scene* s)
 {
     if (!s) return;
+    free(s->ptv);
     free(s->parts); free(s->prox);
     bvh_free(&s->gbvh);
     free(s->mv); free(s->mn); free(s->mf);
@@ -651,6 +674,44 @@ typedef struct {
     grto_counters* c;
 } gps_ctx;
 
+/* ray (full line) against one triangle in double precision; no face culling (tracer.cuh:306) */
+static inline int tri_hit_f64(const float* a, const float* b, const float* c, f3 o, f3 d, double* t)
+{
+    const double e1[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
+    const double e2[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+    const double dd[3] = {d.x, d.y, d.z}, tv[3] = {(double)o.x - a[0], (double)o.y - a[1], (double)o.z - a[2]};
+    const double p[3] = {dd[1] * e2[2] - dd[2] * e2[1], dd[2] * e2[0] - dd[0] * e2[2], dd[0] * e2[1] - dd[1] * e2[0]};
+    const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+    if (det == 0.0) return 0;
+    const double inv = 1.0 / det;
+    const double u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * inv;
+    if (!(u >= 0.0 && u <= 1.0)) return 0;
+    const double q[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const double v = (dd[0] * q[0] + dd[1] * q[1] + dd[2] * q[2]) * inv;
+    if (!(v >= 0.0 && u + v <= 1.0)) return 0;
+    *t = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv;
+    return 1;
+}
+
+/* the instanced icosahedron of particle `id`: nearest and farthest crossing of the ray's line (a convex body: decision (iv),
+ * at most one entry and one exit, however many triangles share the touched edge) */
+static inline int proxy_triangles(const grto_scene* s, uint32_t id, f3 o, f3 d, float* t_entry, float* t_exit)
+{
+    const float* v = &s->ptv[(size_t)id * 36];
+    double tmin = INFINITY, tmax = -INFINITY;
+    int n = 0;
+    for (int f = 0; f < 20; f++) {
+        double t;
+        if (!tri_hit_f64(&v[s->pti[f * 3] * 3], &v[s->pti[f * 3 + 1] * 3], &v[s->pti[f * 3 + 2] * 3], o, d, &t)) continue;
+        tmin = fmin(tmin, t); tmax = fmax(tmax, t);
+        n++;
+    }
+    if (n == 0) return 0;
+    *t_entry = (float)tmin;
+    *t_exit = (float)tmax;
+    return 1;
+}
+
 static inline void gps_test_proxy(gps_ctx* g, const proxy_t* q)
 {
     if (g->c) g->c->proxy_tests++;
@@ -658,7 +719,8 @@ static inline void gps_test_proxy(gps_ctx* g, const proxy_t* q)
     const f3 o_g = matvec(q->A, sub3(g->o, mu));
     const f3 d_g = matvec(q->A, g->d);
     float te, tx;
-    if (!proxy_slabs(o_g, d_g, q->s, &te, &tx)) return;
+    if (g->s->tri_mode) { if (!proxy_triangles(g->s, q->id, g->o, g->d, &te, &tx)) return; }
+    else if (!proxy_slabs(o_g, d_g, q->s, &te, &tx)) return;
     const float t_lo = key_t(g->last_key);
     int in_e = (te >= t_lo) && (te < g->t_hi);
     int in_x = (tx >= t_lo) && (tx < g->t_hi);

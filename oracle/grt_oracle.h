@@ -94,6 +94,10 @@ void        grto_scene_destroy(grto_scene* s);
 void        grto_scene_set_mesh(grto_scene* s, const float* verts, const float* normals, uint32_t nv,
                                 const uint32_t* faces, uint32_t nf);
 void        grto_scene_use_bvh(grto_scene* s, int use_bvh); /* 0 = brute force over all proxies */
+/* checking mode for SURVEY 8(c) decision (v): every proxy test intersects the 20 triangles of the particle's instanced icosahedron
+ * (world-space vertices [n][12][3] by original particle id + 60 indices, supplied by the caller: the tests take them from
+ * oracle/_ref) instead of the ten slabs; NULL = slabs again */
+void        grto_scene_set_proxy_triangles(grto_scene* s, const float* verts, const uint32_t idx[60]);
 
 /* k nearest hits of one traversal (traceGPs + __anyhit__, tracer.cuh:289-326, tracer.cu:124-153) */
 uint32_t grto_trace_gps(const grto_scene* s, const float o[3], const float d[3], float tmin, float tmax,

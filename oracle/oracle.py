@@ -62,6 +62,7 @@ def lib():
         L.grto_scene_create.argtypes = [C.c_void_p, C.c_uint64, C.c_float]
         L.grto_scene_destroy.argtypes = [C.c_void_p]
         L.grto_scene_use_bvh.argtypes = [C.c_void_p, C.c_int]
+        L.grto_scene_set_proxy_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.grto_scene_set_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.grto_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
@@ -151,6 +152,16 @@ class Scene:
 
     def use_bvh(self, flag):
         lib().grto_scene_use_bvh(self._h, int(flag))
+
+    def set_proxy_triangles(self, verts, idx):
+        """Checking mode for decision (v): proxies are intersected as 20 triangles each (verts [n][12][3] world space, idx[60]) instead
+        of ten slabs; verts=None switches back."""
+        if verts is None:
+            lib().grto_scene_set_proxy_triangles(self._h, None, None)
+            return
+        v = np.ascontiguousarray(verts, np.float32).reshape(len(self._parts), 12, 3)
+        i = np.ascontiguousarray(idx, np.uint32).reshape(60)
+        lib().grto_scene_set_proxy_triangles(self._h, v.ctypes.data, i.ctypes.data)
 
     def set_mesh(self, verts, normals, faces):
         v = np.ascontiguousarray(verts, np.float32); n = np.ascontiguousarray(normals, np.float32)

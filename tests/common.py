@@ -42,6 +42,29 @@ def make_scene(seed, n, width, height, **kw):
     return acts, p, sc, to_oracle_params(p), center
 
 
+def usable_cores():
+    """Threads the oracle may usefully run on: the affinity mask capped by the container's cgroup CPU quota (the GPU box shows 256
+    logical cores to a pod whose share is 16; 256 oracle threads there run at half the speed of 16)."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = min(cores, max(1, int(round(int(q) / int(per)))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, int(round(q / per))))
+        except Exception:
+            pass
+    return cores
+
+
 def u8_matches(got_u8, ref_u8, ref_f32, tol=1e-4):
     """Per value: the 8-bit frame EQUALS the oracle's, except where the oracle's radiance lies within `tol` of a
     quantisation step (x * 256 within tol * 256 of an integer), where a radiance difference below the tolerance may
@@ -51,3 +74,26 @@ def u8_matches(got_u8, ref_u8, ref_f32, tol=1e-4):
     x = np.clip(np.asarray(ref_f32, dtype=np.float64), 0.0, 1.0) * 256.0
     near_step = np.abs(x - np.round(x)) <= tol * 256.0
     return (du == 0) | ((du == 1) & near_step)
+
+
+def threshold_flip_explains(sc, op, x, y, gpu_rgb, tol=1e-4, rels=(1e-6, 1e-5, 1e-4)):
+    """A pixel where the GPU and the oracle differ by more than the tolerance: is it a ray that sits ON one of the reference's two
+    hard thresholds?  `if (T > minTransmittance)` (tracer.cuh:341,353) and `if (hitAlpha > alpha_min)` (tracer.cuh:361) are
+    discontinuities of the reference's own function: expf differs in its last bit between glibc, the ROCm device library and CUDA's,
+    the difference is carried by T, and a ray whose T lands within ulps of the threshold consumes one hit more or fewer (<= minT * c
+    = 1e-3 of radiance; alpha_min: <= 0.01 T c).  The oracle re-renders the pixel with minTransmittance and / or alpha_min moved by a
+    relative 1e-6 .. 1e-4: returns the smallest such change (rel, fT, fA) that reproduces the GPU's value within `tol`, else None —
+    a pixel that no such change explains is a real mismatch."""
+    import oracle as O
+    g = np.asarray(gpu_rgb, np.float32)
+    for rel in rels:
+        for fT in (1.0, 1.0 - rel, 1.0 + rel):
+            for fA in (1.0, 1.0 - rel, 1.0 + rel):
+                if fT == 1.0 and fA == 1.0:
+                    continue
+                q = O.Params.from_buffer_copy(op)
+                q.min_transmittance = float(np.float32(op.min_transmittance) * np.float32(fT))
+                q.alpha_min = float(np.float32(op.alpha_min) * np.float32(fA))
+                if float(np.abs(sc.render_pixel(q, x, y) - g).max()) <= tol:
+                    return rel, fT, fA
+    return None

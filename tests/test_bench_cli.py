@@ -40,6 +40,11 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
     assert d["value"] > 5 * cb["value"]
+    # every bench line carries its own correctness figure: this run's GPU frame against the oracle's on the cpu_baseline sample
+    pr = d["parity"]
+    assert pr["pixels"] == 256 * 256 == pr["of_frame_pixels"] and pr["ok"] is True
+    assert pr["u8_mismatch_outside_over_tolerance_pixels"] == 0 and pr["pixels_over_tolerance"] == pr["of_which_threshold_flips"] <= 2
+    assert 0 <= pr["max_abs_off_those_pixels"] <= 1e-4
 
 
 def test_bench_frames_in_flight_on_an_emulated_rank():

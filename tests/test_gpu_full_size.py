@@ -1,10 +1,14 @@
-"""Parity at BASELINE.json's full sizes (C3: 1 M Gaussians at 1920x1080; C5: 3 M at 3840x2160 fisheye) through
-properties that do not need the oracle to render the whole frame:
+"""Parity at BASELINE.json's full sizes (C2: 100 k at 1280x720; C3: 1 M Gaussians at 1920x1080; C4: C3 + the mirror sphere,
+<= 2 bounces; C5: 3 M at 3840x2160 fisheye):
+  * THE WHOLE FRAME AGAINST THE ORACLE, every pixel (round 6; rounds 1-5 sampled 0.2 % of it): radiance within 1e-4 per channel,
+    the 8-bit frame equal to the oracle's except within that tolerance of a quantisation step (compare()); every pixel runs
+    shaders/tracer.cu:17-110 -> tracer.cuh:484-496.  The oracle builds its own midpoint-split BVH and shares no code with the
+    device, so a common-mode error of the four kernels (which share grt_device.h) at scale — index width, tree height, pool
+    exhaustion meeting compositing — shows here and nowhere else;
   * kernel independence: the tile kernel (default), the streaming kernel, the round-based wave kernel and (on a window)
     the per-lane kernel are four separate implementations of the traversal and must agree bit for bit;
   * shard independence: the 8-rank tile split, un-permuted, is the full frame;
-  * schedule independence: frames launched in cost order (scheduling feedback, big-window split) are unchanged;
-  * the oracle itself on sampled windows, including the frame's heaviest tiles (radiance within 1e-4, 8-bit within 1).
+  * schedule independence: frames launched in cost order (scheduling feedback, big-window split) are unchanged.
 """
 import numpy as np
 import pytest
@@ -12,13 +16,70 @@ import torch
 
 import grt
 import tiles
-from common import make_scene
+from common import make_scene, threshold_flip_explains, usable_cores
 from test_gpu_parity import compare
 
 pytestmark = pytest.mark.gpu
 
 
-def test_c3_full_size_properties_and_oracle_windows():
+def whole_frame_against_the_oracle(sc, op, f32, u8, label, **tolerances):
+    """The oracle renders EVERY pixel of the frame (threads = the cores this process may use) and compare() holds on all of them:
+    radiance within 1e-4, 8-bit values equal except within 1e-4 of a quantisation step.  Pinhole frames: a pixel beyond the
+    tolerance must be a ray that sits ON one of the reference's two hard thresholds (common.threshold_flip_explains: the oracle
+    reproduces the GPU's value once minTransmittance or alpha_min moves by a relative 1e-6 .. 1e-4), there may be at most 1e-5 of
+    the frame of them, each within 0.02 (round 6, first whole C3 frame: ONE pixel of 2 073 600, T within 1e-6 of minTransmittance,
+    3.9e-4; every other pixel within 3e-7).  Returns the oracle's counters and the largest radiance difference off those pixels."""
+    import time
+    t0 = time.perf_counter()
+    ref_u8, ref_f32, rc = sc.render(op, threads=usable_cores())
+    dt = time.perf_counter() - t0
+    g = f32.cpu().numpy()
+    d = np.abs(g - ref_f32)
+    over = (d > 1e-4).any(-1)
+    flips = []
+    if not tolerances:
+        ys, xs = np.nonzero(over)
+        assert len(ys) <= max(2, int(1e-5 * over.size)), f"{label}: {len(ys)} pixels beyond 1e-4"
+        for y, x in zip(ys, xs):
+            why = threshold_flip_explains(sc, op, int(x), int(y), g[y, x])
+            assert why is not None, f"{label}: pixel ({x}, {y}) differs by {d[y, x].max():.3e} and no threshold explains it"
+            flips.append((int(x), int(y), float(d[y, x].max()), why))
+        tolerances = dict(max_outlier_frac=len(ys) / over.size, max_outlier=0.02)
+    compare(g, ref_f32, u8, ref_u8, **tolerances)
+    dmax = float(d[~over].max())
+    n8 = int((u8.cpu().numpy() != ref_u8).sum())
+    print(f"{label}: whole frame {op.width}x{op.height} = {op.width * op.height} pixels against the oracle ({dt:.1f} s on "
+          f"{usable_cores()} threads): max |radiance diff| {dmax:.3e} on {int((~over).sum())} pixels, {int(over.sum())} beyond 1e-4 "
+          f"{flips if flips else ''}, {n8} of {ref_u8.size} 8-bit values differ (each within 1e-4 of a quantisation step, or on those pixels)")
+    return rc, dmax
+
+
+def test_c2_full_size_whole_frame_against_the_oracle():
+    """BASELINE config C2: 100 k Gaussians (seed 2), 1280x720 pinhole — all 921 600 pixels against the oracle, and the
+    four kernels bit for bit (the quad kernel is not used at this size; C1's frame in test_gpu_parity runs through it)."""
+    W, H = 1280, 720
+    acts, p, sc, op, _ = make_scene(2, 100_000, W, H)
+    tr = grt.Tracer(0)
+    tr.upload(acts)
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    u8, f32 = tr.render(p, want_f32=True)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    u8, f32 = u8.clone(), f32.clone()
+    for _ in range(3):  # steady state: cost-ordered launches
+        a8, af = tr.render(p, want_f32=True)
+    assert (a8 == u8).all() and (af == f32).all()
+    for kernel in (1, 2, 3):
+        tr.set_option(grt.OPT_KERNEL, kernel)
+        a8, af = tr.render(p, want_f32=True)
+        assert (a8 == u8).all() and (af == f32).all(), kernel
+    rc, _ = whole_frame_against_the_oracle(sc, op, f32, u8, "C2")
+    assert rc["rays"] == W * H and cnt["stall_exits"] == 0 and abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
+    tr.close()
+    sc.close()
+
+
+def test_c3_full_size_whole_frame_against_the_oracle_and_properties():
     W, H = 1920, 1080
     acts, p, sc, op, _ = make_scene(3, 1_000_000, W, H)
     tr = grt.Tracer(0)
@@ -58,15 +119,15 @@ def test_c3_full_size_properties_and_oracle_windows():
             tr.render_tiles(p, 32, 32, rank, world, cnt, out_u8=buf)
         gathered.append(buf)
     assert (tiles.assemble(gathered, W, H, 32) == u8).all()
-    # ---- the oracle on sampled windows ----
-    windows = [(720, 600, 728, 608), (712, 600, 720, 608), (888, 264, 896, 272), (1048, 872, 1056, 880),
-               (0, 0, 32, 32), (944, 524, 976, 556), (1888, 1048, 1920, 1080), (300, 900, 332, 916)]
-    hits = 0
-    for (x0, y0, x1, y1) in windows:
-        ref_u8, ref_f32, rc = sc.render(op, window=(x0, y0, x1, y1), threads=8)
-        compare(f32[y0:y1, x0:x1], ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1])
-        hits += rc["hit_evals"]
-    assert hits > 20000  # the sample is not empty space
+    # ---- the oracle on the WHOLE frame (2 073 600 pixels) ----
+    rc, _ = whole_frame_against_the_oracle(sc, op, f32, u8, "C3")
+    tr.set_option(grt.OPT_COUNTERS, 1)
+    tr.render(p)
+    cnt = tr.counters()
+    tr.set_option(grt.OPT_COUNTERS, 0)
+    # (consumed hits may differ where expf's last bit moves a ray across T = minTransmittance: test_c1's allowance)
+    assert rc["rays"] == W * H and rc["hit_evals"] > 30 * W * H and cnt["stall_exits"] == 0
+    assert abs(cnt["hit_evals"] - rc["hit_evals"]) <= 1e-4 * rc["hit_evals"]
     tr.close()
     sc.close()
 
@@ -79,36 +140,13 @@ def test_c5_full_size_fisheye_kernel_and_shard_independence():
     u8, f32 = tr.render(p, want_f32=True)
     u8, f32 = u8.clone(), f32.clone()
     assert (u8[:8, :8] == 0).all()  # fisheye: r > 1 is black
-    # ---- the oracle at size (device and host rays differ in the last bits of sinf / cosf / asinf / atan2f here, and only
-    #      here): the centre, the rim (r ~ 1: the window straddles the edge of the image circle), interior windows, and the
-    #      heaviest of a grid of candidate windows (most exact proxy tests) — with test_fisheye's near-tie allowance ----
-    windows = [(W // 2 - 8, H // 2 - 8, W // 2 + 8, H // 2 + 8), (3272, 1836, 3288, 1852), (1912, 8, 1928, 24),
-               (1200, 700, 1216, 716), (2600, 1500, 2616, 1516), (2872, 1072, 2888, 1088)]
-    tr.set_option(grt.OPT_COUNTERS, 1)
-    best, best_cost = None, -1
-    w8 = torch.zeros_like(u8)
-    for gy in range(6):
-        for gx in range(8):
-            x0, y0 = 480 + gx * 360, 180 + gy * 300
-            tr.render(p, window=(x0, y0, x0 + 16, y0 + 16), out_u8=w8)
-            c = tr.counters()["proxy_tests"]
-            if c > best_cost:
-                best, best_cost = (x0, y0, x0 + 16, y0 + 16), c
-    tr.set_option(grt.OPT_COUNTERS, 0)
-    windows.append(best)
-    hits = n_px = n_bad = 0
-    for (x0, y0, x1, y1) in windows:
-        ref_u8, ref_f32, rc = sc.render(op, window=(x0, y0, x1, y1), threads=8)
-        g = f32[y0:y1, x0:x1].cpu().numpy()
-        d = np.abs(g - ref_f32[y0:y1, x0:x1])
-        n_bad += int((d > 1e-4).any(-1).sum()); n_px += d.shape[0] * d.shape[1]
-        compare(g, ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1], max_outlier_frac=1.0, max_outlier=0.08)
-        hits += rc["hit_evals"]
-    assert n_bad <= max(1, int(2e-3 * n_px)), (n_bad, n_px)  # near-tie order flips only (test_fisheye: 2e-4 of a frame)
-    assert hits > 20000 and best_cost > 0
+    # ---- the oracle on the WHOLE frame (8 294 400 pixels, 6.5 M of them inside the image circle).  Device and host rays differ
+    #      in the last bits of sinf / cosf / asinf / atan2f here, and only here: a near-tie between two events may flip on a
+    #      few pixels (test_fisheye's allowance: at most 2e-4 of the pixels beyond 1e-4, each bounded by 0.08; measured 7.2e-5: 597 pixels) ----
+    rc, _ = whole_frame_against_the_oracle(sc, op, f32, u8, "C5", max_outlier_frac=2e-4, max_outlier=0.08)
+    assert 0.75 * W * H < rc["rays"] < 0.80 * W * H and rc["hit_evals"] > 10 * rc["rays"]  # pi / 4 of the frame spawns rays
     rim = f32[1836:1852, 3272:3288].cpu().numpy()
-    assert (rim[-1, -1] == 0).all()  # the rim window straddles r = 1 (corner radii 0.993 / 1.009); at r ~ 1 the rays look
-    # sideways past the scene, so its live pixels are dark too: the oracle agreeing on them is the check
+    assert (rim[-1, -1] == 0).all()  # this window straddles r = 1 (corner radii 0.993 / 1.009): outside is black
     sc.close()
     for kernel in (2, 3):
         tr.set_option(grt.OPT_KERNEL, kernel)
@@ -132,8 +170,7 @@ def test_c4_full_size_mirror_sphere_through_the_obj_path(tmp_path):
     (src/geometry/Primitives.cpp:63-140) written once as OBJ with normals and loaded through the OBJ path (Y flip,
     Primitives.cpp:175,179; un-indexed soup), placed at 0.25 lookat + 0.75 eye (src/GaussianTracer.cpp:630-638),
     MIRROR, bounce cap 2.  The default pipeline (tile kernel + wavefront bounces), the streaming-kernel pipeline and,
-    on windows with mirror pixels, the per-lane megakernel agree bit for bit; the oracle is run on sampled windows
-    inside, at the rim of and outside the sphere."""
+    on windows with mirror pixels, the per-lane megakernel agree bit for bit; the oracle renders the whole frame."""
     W, H = 1920, 1080
     acts, p, sc, op, center = make_scene(3, 1_000_000, W, H, mesh_type=grt.MIRROR, max_bounces=2)
     v, n, f = grt.primitive_mesh(grt.PRIM_SPHERE)
@@ -166,13 +203,9 @@ def test_c4_full_size_mirror_sphere_through_the_obj_path(tmp_path):
         tr.render(p, window=win, out_u8=w8, out_f32=wf)
         assert (w8[y0:y1, x0:x1] == u8[y0:y1, x0:x1]).all() and (wf[y0:y1, x0:x1] == f32[y0:y1, x0:x1]).all(), win
     tr.set_option(grt.OPT_KERNEL, 0)
-    mirror_segments = 0
-    for (x0, y0, x1, y1) in [(952, 532, 968, 548), (700, 500, 716, 516), (1180, 640, 1196, 656), (600, 300, 616, 316),
-                             (560, 532, 576, 548), (40, 40, 56, 56)]:
-        ref_u8, ref_f32, rc = sc.render(op, window=(x0, y0, x1, y1), threads=8)
-        compare(f32[y0:y1, x0:x1], ref_f32[y0:y1, x0:x1], u8[y0:y1, x0:x1], ref_u8[y0:y1, x0:x1])
-        mirror_segments += rc["segments"] - rc["rays"]
-    assert mirror_segments > 3 * 256  # most sampled windows look into the mirror
+    # ---- the oracle on the WHOLE frame: every pixel through mesh closest hit, mirror bounce and both Gaussian segments ----
+    rc, _ = whole_frame_against_the_oracle(sc, op, f32, u8, "C4")
+    assert rc["segments"] - rc["rays"] > 400_000 and rc["segments"] == cnt["segments"]  # the sphere's pixels carry a second segment
     tr.close()
     sc.close()
 

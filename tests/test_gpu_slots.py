@@ -338,3 +338,54 @@ def test_spatial_splits_are_pure_acceleration_structure(fisheye):
         compare(f32, ref_f32, u8, ref_u8)
         assert rc["hit_evals"] == cnts[(0, 0)]["hit_evals"]
     sc.close()
+
+
+def test_tree_rotations_rederive_levels_and_height_and_keep_the_frame():
+    """GRT_OPT_BVH_ROTATIONS: a rotation pushes the swapped sibling one level down, so a rotated tree can be
+    DEEPER than the refit's height — which sizes the per-lane kernel's LDS stack (GRT_OPT_KERNEL = 1), decides whether the tile kernel's
+    depth-first stack fits and bounds the wave kernel's stack.  Behind every sweep the build now numbers the levels afresh and reports
+    the new root level as the height.  A needle / sheet scene (its tree holds pieces: the only trees rotated by default) and the same
+    scene without splits, with 0, 1 (default for pieces) and 3 sweeps: the depth WALKED on the host never exceeds the reported height,
+    every kernel renders the same bytes with the same hit counters whatever the sweeps, and the frame is the oracle's."""
+    W, H = 160, 120
+    raw = grt.synth_scene(83, 30000)
+    rng = np.random.default_rng(11)
+    raw["scale"] = (raw["scale"] + rng.normal(0.0, 1.6, size=raw["scale"].shape)).astype(np.float32)
+    acts = grt.activate(raw)
+    center = grt.gaussian_center(acts["pos"])
+    p = grt.default_params(W, H, center)
+    base = None
+    heights = {}
+    for split in (8, 0):
+        for sweeps in (0, -1, 1, 3):
+            for kernel in ((0, 1, 2, 3) if sweeps in (0, 3) else (0, 1)):
+                t = grt.Tracer(0)
+                t.set_option(grt.OPT_SPLIT, split)
+                t.set_option(grt.OPT_BVH_ROTATIONS, sweeps)
+                t.set_option(grt.OPT_KERNEL, kernel)
+                t.upload(acts)
+                info = t.bvh_info()
+                walked = t.bvh_depth_walked()
+                assert 0 < walked <= info["height"], (split, sweeps, walked, info["height"])
+                heights[(split, sweeps)] = (walked, info["height"])
+                t.set_option(grt.OPT_COUNTERS, 1)
+                u8, f32 = t.render(p, want_f32=True)
+                cnt = t.counters()
+                t.check()
+                if base is None:
+                    base = (u8.clone(), f32.clone(), cnt["hit_evals"])
+                assert bool((u8 == base[0]).all()) and bool((f32 == base[1]).all()), (split, sweeps, kernel)
+                assert cnt["hit_evals"] == base[2] and cnt["stall_exits"] == 0, (split, sweeps, kernel)
+                t.close()
+    # behind a sweep the height reported IS the walked depth (levels re-derived over the tree as it stands; the refit's own height of
+    # an unrotated tree still counts the bottom levels that the collapse into leaf ranges removed: an upper bound); the default for a
+    # tree with pieces is one sweep, and a tree without pieces is left alone by default
+    for k, (walked, h) in heights.items():
+        assert (walked == h) if k[1] > 0 else (walked <= h), (k, walked, h)
+    print("tree depth walked / height reported, by (split, sweeps):", heights)
+    assert heights[(8, -1)] == heights[(8, 1)] and heights[(0, -1)] == heights[(0, 0)]
+    sc = O.Scene(acts_to_particles(acts))
+    ref_u8, ref_f32, rc = sc.render(to_oracle_params(p), threads=8)
+    compare(base[1], ref_f32, base[0], ref_u8)
+    assert rc["hit_evals"] == base[2]
+    sc.close()

@@ -311,3 +311,75 @@ def test_ref_proxy_vertices_inside_oracle_aabb_and_on_slab_planes():
             g = A @ (w.astype(np.float64) - p["pos"][0].astype(np.float64))
             m = np.max(np.abs(n.astype(np.float64) @ g))
             assert abs(m - s) < 2e-3 * s
+
+
+# ---------------------------------------------------------------------------------------------
+# decision (v) on whole frames: ten slabs in Gaussian space == the reference's 20 instanced triangles
+# ---------------------------------------------------------------------------------------------
+def _small_scene(n=300, seed=21):
+    rng = np.random.default_rng(seed)
+    pos = f32(rng.normal(0.0, 0.45, size=(n, 3)))
+    f_dc = f32(rng.uniform(-1.5, 1.5, size=(n, 3)))
+    f_rest = f32(rng.normal(0.0, 0.1, size=(n, 45)))
+    logit = f32(rng.normal(1.0, 2.0, size=n))
+    log_scale = f32(rng.normal(np.log(0.12), 0.6, size=(n, 3)))  # anisotropic: axes differ by e^(+-0.6)
+    rot = f32(rng.normal(size=(n, 4)))
+    return O.activate(pos, f_dc, f_rest, logit, log_scale, rot)
+
+
+def _ref_instanced_icosahedra(parts, alpha_min=0.01):
+    """World-space vertices [n][12][3] of every particle's proxy: the reference's OWN mesh (src/geometry/Icosahedron.h:13-37) through the
+    reference's OWN instance transform T * (R * S) (src/GaussianTracer.cpp:304-311: glm translate / mat4_cast / scale with
+    s = sqrtf(2 logf(opacity / alpha_min)), :306), both compiled from the reference's sources in oracle/_ref."""
+    R = O.ref()
+    base = np.zeros(36, np.float32); idx = np.zeros(60, np.uint32)
+    R.ref_icosahedron(ptr(base), idx.ctypes.data_as(C.c_void_p))
+    base = base.reshape(12, 3)
+    out = np.zeros((len(parts), 12, 3), np.float32)
+    for i, p in enumerate(parts):
+        if not p["opacity"] > alpha_min:
+            continue  # NaN / zero transform in the reference: unhittable (decision (vi)); the oracle never tests it
+        s = np.float32(np.sqrt(np.float32(2.0) * np.float32(np.log(np.float32(p["opacity"] / np.float32(alpha_min))))))
+        assert abs(float(s) - O.lib().grto_proxy_scale(float(p["opacity"]), alpha_min)) <= 2e-7 * float(s)
+        for k in range(12):
+            w = np.zeros(3, np.float32)
+            R.ref_instance_vertex(ptr(f32(p["pos"])), ptr(f32(p["scale"])), ptr(f32(p["quat"])), C.c_float(float(s)), ptr(f32(base[k])), ptr(w))
+            out[i, k] = w
+    return out, idx
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", ["pinhole", "fisheye", "mirror", "glass_sh2"])
+def test_decision_v_slabs_equal_the_reference_built_triangles_on_whole_frames(mode):
+    """SURVEY 8(c) decision (v) replaces OptiX's ray / triangle tests against the instanced icosahedron by ten slab tests in Gaussian
+    space; until round 6 the only evidence for it on whole frames was a probe the survey session ran.  Here the oracle renders small
+    frames twice: with the slabs, and with every proxy intersected as its 20 TRIANGLES — vertices from the reference's own mesh and
+    instance transform (oracle/_ref), double-precision Moeller-Trumbore, no culling, brute force over all particles (no BVH of ours
+    in the way) — feeding the same k-buffer and integrator (shaders/tracer.cu:136-153, tracer.cuh:328-373).  0 differing 8-bit
+    levels, radiance within 1e-6, identical hit counts."""
+    parts = _small_scene()
+    W = H = 48
+    eye = f32([0, 0, 3]); look = f32(parts["pos"].mean(0)); up = f32([0, 1, 0])
+    U, V, Wv = O.uvw_frame(eye, look, up, 60.0, 1.0)
+    kw = dict(pinhole={}, fisheye=dict(fisheye=True), mirror=dict(mesh_type=0, max_bounces=4),
+              glass_sh2=dict(mesh_type=2, max_bounces=6, sh_degree=2))[mode]
+    prm = O.make_params(W, H, eye, U, V, Wv, **kw)
+    sc = O.Scene(parts)
+    if mode in ("mirror", "glass_sh2"):
+        # a quad in the middle of the cloud with NON-flat vertex normals (the probe's set-up): rays bounce / refract into the Gaussians behind
+        mv = f32([[-0.9, -0.9, 0.2], [0.9, -0.9, 0.2], [0.9, 0.9, 0.1], [-0.9, 0.9, 0.3]])
+        mn = f32([[0.1, 0.0, 1.0], [-0.2, 0.1, 1.0], [0.0, -0.15, 1.0], [0.15, 0.1, 1.0]])
+        mn = f32(mn / np.linalg.norm(mn, axis=1, keepdims=True))
+        sc.set_mesh(mv, mn, np.uint32([[0, 1, 2], [0, 2, 3]]))
+    u8_s, f_s, c_s = sc.render(prm, threads=8)
+    verts, idx = _ref_instanced_icosahedra(parts)
+    sc.set_proxy_triangles(verts, idx)
+    sc.use_bvh(False)
+    u8_t, f_t, c_t = sc.render(prm, threads=8)
+    sc.close()
+    assert c_s["hit_evals"] > 8 * W * H * (0.5 if mode == "fisheye" else 1.0)  # the frames are full of Gaussians
+    assert c_s["hit_evals"] == c_t["hit_evals"] and c_s["segments"] == c_t["segments"]
+    assert (u8_s == u8_t).all(), f"{(u8_s != u8_t).sum()} 8-bit levels differ"
+    assert float(np.abs(f_s - f_t).max()) <= 1e-6
+    if mode != "pinhole":
+        assert c_s["segments"] > c_s["rays"] or mode == "fisheye"
