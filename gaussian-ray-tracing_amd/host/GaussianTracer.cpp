@@ -239,8 +239,8 @@ void HIPOutputBuffer::unmap()
 const std::vector<unsigned char>& HIPOutputBuffer::download()
 {
     m_copy.resize((size_t)m_width * m_height * 3);
-    const uchar3* src = m_gl ? mapGL() : m_device; // (GL: the PBO is mapped for the copy and handed back)
+    const uchar3* src = m_gl ? mapGL() : m_device; // (GL: the PBO is mapped for the copy and handed back — also when the copy throws)
+    struct Unmap { HIPOutputBuffer* b; ~Unmap() { if (b) b->unmapGL(); } } guard{m_gl ? this : nullptr};
     hipglue::copyToHost(m_copy.data(), src, m_copy.size());
-    if (m_gl) unmapGL();
     return m_copy;
 }

@@ -5,7 +5,7 @@
 //     host mirror; unmap() enqueues the device -> host copy on the same stream, and after render()'s stream synchronisation
 //     (src/GaussianTracer.cpp:537) getHostPointer() is the frame the display uploads (Display.h).  getPBO() = 0.
 //   * GL INTEROP (builds with -DGRT_WITH_GL, HIPOutputBufferGL.cpp; the reference's only form): a GL pixel-buffer object
-//     registered with HIP — glGenBuffers / glBufferData, hipGraphicsGLRegisterBuffer (write-discard); map() =
+//     registered with HIP — glGenBuffers / glBufferData, hipGraphicsGLRegisterBuffer (readable: download() maps it too); map() =
 //     hipGraphicsMapResources + hipGraphicsResourceGetMappedPointer on the stream, unmap() = hipGraphicsUnmapResources;
 //     getPBO() is the object GLDisplay::display() binds as GL_PIXEL_UNPACK_BUFFER.  Needs a current GL context on a GPU that
 //     drives it (hipGLGetDevices); unlike the reference, resize() and the destructor unregister and delete the old object.

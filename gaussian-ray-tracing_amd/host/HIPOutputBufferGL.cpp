@@ -50,7 +50,9 @@ void HIPOutputBuffer::resizeGL(int32_t width, int32_t height)
     glBindBuffer(GL_ARRAY_BUFFER, 0u);
     glOk("pixel-buffer object");
     hipGraphicsResource_t res = nullptr;
-    hipOk(hipGraphicsGLRegisterBuffer(&res, m_pbo, hipGraphicsRegisterFlagsWriteDiscard), "hipGraphicsGLRegisterBuffer");
+    // (flags None, not WriteDiscard as src/CUDAOutputBuffer.cpp:38-43 registers its PBO: download() maps the buffer to READ the frame
+    //  back, and what a write-discard resource holds after a map is undefined)
+    hipOk(hipGraphicsGLRegisterBuffer(&res, m_pbo, hipGraphicsRegisterFlagsNone), "hipGraphicsGLRegisterBuffer");
     m_gfx = res;
 }
 

@@ -8,10 +8,13 @@ GL context, says so and exits 0."""
 import os
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "gaussian-ray-tracing_amd")
 
 
+@pytest.mark.skipif(not os.path.exists("/usr/include/GL/gl.h"), reason="no OpenGL headers on this box: the optional viewer target is not built")
 def test_gl_interop_glue_compiles_links_and_runs_without_a_display():
     r = subprocess.run(["make", "-C", os.path.join(PKG, "host"), "gl", "-j4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
