@@ -549,6 +549,7 @@ static void free_slot_state(grt_ctx* c)
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_cost); (void)hipFree(c->d_order); (void)hipFree(c->d_cost_dil); (void)hipFree(c->d_ord_scratch); (void)hipFree(c->d_qparts); (void)hipFree(c->d_qpcount);
     (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_qcount); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
+    (void)hipFree(c->d_bverdict); (void)hipFree(c->d_qunit); (void)hipFree(c->d_qskip); (void)hipFree(c->d_heavy_a);
     reap_old_pools(c, true, nullptr);
     (void)hipFree(c->d_ovf); (void)hipFree(c->d_ovf_next);
     (void)hipFree(c->d_err);
@@ -621,8 +622,10 @@ int grt_set_option(grt_ctx* c, int option, int value)
         if (value < 0 || value > kMaxBundleRounds) { c->err = "GRT_OPT_BUNDLE_ROUNDS must be 0.." + std::to_string(kMaxBundleRounds); return GRT_ERR_INVALID; }
         c->opt_bundle_rounds = value;
     }
-    else if (option == GRT_OPT_BUNDLE_BUDGET) { c->opt_bundle_budget = std::max(1, value); }
+    else if (option == GRT_OPT_BUNDLE_BUDGET) { c->opt_bundle_budget = std::max(1, value); c->bv_epoch = ~0ull; /* (a verdict is a statement about THIS budget) */ }
     else if (option == GRT_OPT_LANE_BUDGET) { c->opt_lane_budget = std::max(1, value); }
+    else if (option == GRT_OPT_MESH_PRIMARY_WAVE) { c->opt_mesh_primary_wave = value ? 1 : 0; }
+    else if (option == GRT_OPT_BUNDLE_PREDICT) { c->opt_bundle_predict = value ? 1 : 0; c->bv_epoch = ~0ull; /* (verdicts start afresh) */ }
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
@@ -1478,6 +1481,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.bundle_budget = (uint32_t)c->opt_bundle_budget * (a.p.type == GRT_GLASS ? 2u : 1u);
     a.lane_budget = (uint32_t)c->opt_lane_budget;
     a.single_own_mesh = 0;
+    a.mesh_primary_wave = c->opt_mesh_primary_wave ? 1u : 0u;
+    a.mstack_depth = sc->mbvh.height + 2u;
     a.single_look = (float)c->opt_single_look / 1024.0f;
     a.single_band = (float)c->opt_single_band / 1024.0f;
     if (sc->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)
@@ -1486,6 +1491,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         const size_t need = ((size_t)a.n_blocks * 4 + parts_extra_cap(a.n_blocks * 4u)) * 64;
         if (c->wf_cap < need) {
             (void)hipFree(c->d_prec); (void)hipFree(c->d_queue); (void)hipFree(c->d_heavy); (void)hipFree(c->d_fqueue);
+            (void)hipFree(c->d_qunit); (void)hipFree(c->d_qskip); (void)hipFree(c->d_heavy_a); // (sized by the queues: re-made with the verdicts below)
+            c->d_qunit = c->d_qskip = c->d_heavy_a = nullptr;
             c->d_prec = c->d_queue = c->d_fqueue = nullptr;
             c->d_heavy = nullptr;
             c->wf_cap = 0;
@@ -1500,7 +1507,39 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.queue_alt = c->d_queue + c->wf_cap * 4;
         a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
+    a.bverdict = nullptr; a.qunit = nullptr; a.qskip = nullptr; a.heavy_a = nullptr; a.hcount_a = nullptr; a.bverdict_decay = 0;
     const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max, sc->gbvh.n_prims);
+    if (sc->n_faces && a.mode != 2 && tile_kernel && c->opt_bundle_predict && c->opt_bundle_rounds > 0 && c->wf_cap) {
+        // bundle verdicts (RenderArgs::bverdict): one word per 8x8 tile of the launch; they belong to a launch geometry and a scene —
+        // anything else starts from "every tile is a bundle" — and are used up under a view that changes
+        const uint32_t nu = a.n_blocks * 4u;
+        const uint64_t sig[6] = {a.mode | ((uint64_t)nu << 8), a.n_blocks, ((uint64_t)a.p.width << 32) | a.p.height,
+                                 ((uint64_t)a.x0 << 48) ^ ((uint64_t)a.y0 << 32) ^ ((uint64_t)a.x1 << 16) ^ a.y1,
+                                 ((uint64_t)a.first_tile << 32) | a.tile_stride, ((uint64_t)a.tile_w << 32) | a.tile_h};
+        const size_t chunks = c->wf_cap / 64;
+        bool fresh = false;
+        if (c->bv_cap < nu || !c->d_qunit) {
+            (void)hipFree(c->d_bverdict); (void)hipFree(c->d_qunit); (void)hipFree(c->d_qskip); (void)hipFree(c->d_heavy_a);
+            c->d_bverdict = c->d_qunit = c->d_qskip = c->d_heavy_a = nullptr;
+            c->bv_cap = 0;
+            CHK(c, hipMalloc(&c->d_bverdict, sizeof(uint32_t) * nu));
+            CHK(c, hipMalloc(&c->d_qunit, sizeof(uint32_t) * chunks));
+            CHK(c, hipMalloc(&c->d_qskip, sizeof(uint32_t) * chunks));
+            CHK(c, hipMalloc(&c->d_heavy_a, sizeof(uint32_t) * c->wf_cap));
+            c->bv_cap = nu;
+            fresh = true;
+        }
+        if (fresh || memcmp(sig, c->bv_sig, sizeof(sig)) != 0 || c->bv_epoch != sc->scene_epoch) {
+            CHK(c, hipMemsetAsync(c->d_bverdict, 0, sizeof(uint32_t) * nu, s)); // (on the frame's stream: ordered against its kernels)
+            memcpy(c->bv_sig, sig, sizeof(sig));
+            c->bv_epoch = sc->scene_epoch;
+            c->bv_params_valid = false;
+        }
+        a.bverdict = c->d_bverdict; a.qunit = c->d_qunit; a.qskip = c->d_qskip; a.heavy_a = c->d_heavy_a;
+        a.bverdict_decay = (c->bv_params_valid && memcmp(&c->bv_params, &a.p, sizeof(grt_params)) == 0) ? 0u : 1u;
+        c->bv_params = a.p;
+        c->bv_params_valid = true;
+    }
     // allocations first (they may synchronise): eye records of this slot, overflow pool
     const uint32_t m = sc->gbvh.n_prims;
     const bool want_erec = a.mode != 2 && m && c->opt_kernel != 1 && c->opt_kernel != 2;
@@ -1607,6 +1646,20 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     }
     int rc = launch_render(a, c->opt_counters != 0, c->opt_kernel, depth, tile_kernel, s, &aux, &c->err);
     CHK(c, hipEventRecord(c->ev1, s));
+    {
+        static const bool dbg_wf = getenv("GRT_DEBUG_LAUNCH") != nullptr; // mesh frames: what went through the wavefront stages (grt_internal.h: kWfCounters)
+        if (dbg_wf && rc == GRT_OK && a.qcount) {
+            uint32_t q[kWfCounters];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(q, a.qcount, sizeof(q), hipMemcpyDeviceToHost);
+            std::string t = "grt wavefront: chunks after primary / bundle rounds:";
+            for (int k = 0; k <= kMaxBundleRounds; k++) t += " " + std::to_string(q[k]);
+            t += " | heavy rays per round:";
+            for (int k = 0; k < kMaxBundleRounds; k++) t += " " + std::to_string(q[kMaxBundleRounds + 1 + k]);
+            t += " | retry queue: " + std::to_string(q[2 * kMaxBundleRounds + 1]) + " | early list (tiles known not to be bundles): " + std::to_string(q[3 * kMaxBundleRounds + 3]) + " rays";
+            fprintf(stderr, "%s\n", t.c_str());
+        }
+    }
     c->have_timing = (rc == GRT_OK);
     // ---- behind the frame, outside its timing (grt_last_kernel_ms brackets ev0..ev1; the feedback kernels below are
     //      ~60 us per frame under a moving camera and are what `frame ms - kernel ms` of bench.py's orbit leg shows) ----

@@ -143,7 +143,19 @@ struct RenderArgs {
                               // (state at the start of that iteration), finished by the last one-ray-per-wave launch
     uint32_t* fcount;
     uint32_t lane_budget;     // k_bounce: iterations one Gaussian segment may take before its ray goes to the retry queue
+    uint32_t mesh_primary_wave; // stage 1 of mesh frames: 1 = one walk of the mesh tree per 8x8 tile (k_primary_mesh_wave), 0 = one per lane
+    uint32_t mstack_depth;      // ... entries of a wave's stack: the mesh tree's height + 2
     uint32_t single_own_mesh; // mode 2: the rays come from the retry queue (no mesh-hit record: the wave traces the mesh)
+    // bundle verdicts (mesh frames on the tile kernel, first bundle round; GRT_OPT_BUNDLE_PREDICT): a tile whose bounced rays gave up as
+    // a bundle is remembered, and the next frames send its continuation rays one per wave AT ONCE — on a list of their own that the
+    // one-ray-per-wave kernel works off BESIDE the bundle kernel (second stream) instead of behind it, and without the budget-long bundle
+    // that is thrown away.  Same rays through the same two kernels as before, so the same pixels.
+    uint32_t* bverdict;       // [n_units] frames the verdict still holds; 0 = the tile's continuation rays are traced as a bundle
+    uint32_t* qunit;          // [chunks of the first queue] the unit (8x8 tile) whose primary-stage wave wrote the chunk
+    uint32_t* qskip;          // [chunks] 1 = the chunk's rays are on the early list: the bundle kernel leaves it alone (written by k_queue_mesh)
+    uint32_t* heavy_a;        // the early list: entries of queue_in (k_queue_mesh writes it, a mode-2 launch reads it as its `heavy`)
+    uint32_t* hcount_a;
+    uint32_t bverdict_decay;  // the view differs from the one the verdicts were given under: a verdict that is used loses one of its frames
     float single_look, single_band; // look-ahead / band of the one-ray-per-wave mode
 };
 
@@ -195,7 +207,9 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
 // round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the retry queue, [2R+2 .. 3R+1] the draw
 // counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
-constexpr int kWfCounters = 3 * kMaxBundleRounds + 3;
+//, [3R+3] rays on the EARLY heavy list (bundle verdicts: RenderArgs::bverdict), [3R+4] its draw counter
+constexpr int kWfCounters = 3 * kMaxBundleRounds + 5;
+constexpr uint32_t kBundleVerdictFrames = 8u; // frames under a CHANGING view that a tile's "not a bundle" verdict holds before its rays are tried as a bundle again (a standing view keeps it)
 constexpr uint32_t kTileOvfEntries = 96u; // per-lane capacity of a window-overflow bag
 constexpr uint32_t kTileOvfSub = 32u;     // ... handed out this many entries at a time: a chunk of the pool = 32 entries x 64 lanes
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfSub * 64 * 16; // 32 KiB; a tile holds up to kTileOvfEntries / kTileOvfSub of them
@@ -352,10 +366,18 @@ struct grt_ctx {
     bool cost_zeroed = false, ovf_zeroed = false; // d_cost / d_ovf_next were zeroed behind the last frame
     // wavefront buffers (allocated on first mesh frame)
     float4 *d_prec = nullptr, *d_queue = nullptr; // d_queue: two queues (ping-pong between the stages)
+    uint32_t *d_bverdict = nullptr, *d_qunit = nullptr, *d_qskip = nullptr, *d_heavy_a = nullptr; // bundle verdicts (RenderArgs::bverdict)
+    uint32_t bv_cap = 0;          // units d_bverdict holds
+    uint64_t bv_sig[6] = {0, 0, 0, 0, 0, 0}; // launch geometry the verdicts belong to
+    uint64_t bv_epoch = ~0ull;    // scene epoch they belong to
+    grt_params bv_params;         // view of the last mesh frame that used or gave verdicts
+    bool bv_params_valid = false;
     uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)
     int opt_bundle_rounds = 2; // bounce iterations traced by the wave-per-bundle kernel before the per-lane kernel finishes
-    int opt_bundle_budget = 896; // (C4 sweep, profiles/tools/tune_c4.py: 3.30 ms at 768..896, 3.40 at 1024, 4.1 at 640: below ~700 too many bundles end one ray per wave)
+    int opt_bundle_budget = 1400; // (round 6, with bundle verdicts: C4 2.55 ms at 896, 2.48 at 1100, 2.42 at 1300, 2.40 at 1400-1500, 2.46 at 1700; a glass sphere 4.8 / 4.4 / 4.3 / 4.4 at 896 / 1300 / 1400 / 1500 — the bundles run BESIDE the one-ray-per-wave kernel now, so a longer bundle costs nothing until it outlasts that kernel; round 3 without verdicts: 896, profiles/tools/tune_c4.py)
     int opt_lane_budget = 128;
+    int opt_bundle_predict = 1; // GRT_OPT_BUNDLE_PREDICT
+    int opt_mesh_primary_wave = 1; // GRT_OPT_MESH_PRIMARY_WAVE
     int opt_single_look = 256, opt_single_band = 256; // 1/1024
     uint32_t* d_heavy = nullptr;
     float4* d_fqueue = nullptr;

@@ -299,6 +299,23 @@ __global__ __launch_bounds__(kBlock) void k_queue_mesh(const RenderArgs a)
     a.prec[i * 3 + 0] = make_float4(seg_tmax, __uint_as_float(flags), curO.x, curO.y);
     a.prec[i * 3 + 1] = make_float4(curO.z, curD.x, curD.y, curD.z);
     a.prec[i * 3 + 2] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    // Bundle verdicts (first round only): a wave is one chunk = the bounced rays of one 8x8 tile.  A tile that gave up as a bundle in an
+    // earlier frame (RenderArgs::bverdict) has its rays put on the early list of the one-ray-per-wave kernel here, and its chunk is
+    // marked for the bundle kernel to skip: the two kernels then run side by side, and the bundle that would be thrown away is not run.
+    if (a.bverdict) {
+        const uint32_t chunk = (uint32_t)(i >> 6);
+        const uint32_t u = a.qunit[chunk];
+        const uint32_t v = a.bverdict[u];
+        if (lane == 0) a.qskip[chunk] = v ? 1u : 0u;
+        if (v) {
+            const uint64_t vm = __ballot(have_ray);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.hcount_a, (uint32_t)__popcll(vm));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (have_ray) a.heavy_a[base + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            if (a.bverdict_decay && lane == 0) a.bverdict[u] = v - 1u; // under a changing view a verdict is used up; a standing one keeps it
+        }
+    }
     if (COUNT) {
         uint32_t x = c.node_visits;
         for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
@@ -351,6 +368,164 @@ __global__ __launch_bounds__(kBlock) void k_primary_mesh(const RenderArgs a)
         const MeshHit mh = mesh_closest<COUNT>(a, stk, eye, dir, kTraceMeshTmin, kTraceMeshTmax, c);
         mesh_shade(a, mh, eye, dir, state, seg_tmax, normal, curO, curD, numBounces);
     }
+    const size_t i = ((size_t)blk * kBlock + threadIdx.x) * 3;
+    const uint32_t flags = (uint32_t)state | (numBounces << 8) | ((have_ray ? 1u : 0u) << 16);
+    a.prec[i + 0] = make_float4(seg_tmax, __uint_as_float(flags), curO.x, curO.y);
+    a.prec[i + 1] = make_float4(curO.z, curD.x, curD.y, curD.z);
+    a.prec[i + 2] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    if (COUNT) {
+        uint32_t v[2] = {c.rays, c.node_visits};
+        for (int k = 0; k < 2; k++) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+            if (lane == 0 && x) {
+                atomicAdd(&a.counters[k == 0 ? 0 : 4], (unsigned long long)x);
+                if (k == 1) atomicAdd(&a.counters[6], (unsigned long long)x);
+            }
+        }
+    }
+}
+
+// ---- stage 1, wave-cooperative (round 6): the 64 camera rays of an 8x8 tile are almost parallel and meet the same few triangles.
+// k_primary_mesh walks the mesh tree once PER LANE (a dependent vector load per node, per-lane stacks in LDS: 246 us on the 1080p
+// frame with the 32 k-face sphere, a fifth of that frame's Gaussian stage — waves whose rays graze the sphere's limb take up to ten
+// times the mean).  Here the wave walks it ONCE: the node — both children's boxes in one 64-B record — comes by a scalar load, every
+// lane tests the two boxes against ITS ray and its own current closest hit, a child is entered when any lane wants it (nearer child
+// first by the first voting lane's order), the far one waits on ONE stack per wave; a leaf's triangles come by scalar loads too and
+// every lane runs the same Moeller-Trumbore test with the same closest-hit rule as mesh_closest_t (grt_mesh.h).  A lane visits a
+// superset of the nodes its own walk would visit, the closest hit and the tie rule (lowest face at equal t) do not depend on the
+// order, and (t, u, v) come from the same arithmetic on the same triangle: the SAME record, bit for bit
+// (tests/test_gpu_parity.py: every mesh test runs both kernels).  Reference: traceMesh + __closesthit__ / __miss__,
+// shaders/tracer.cuh:266-287, shaders/tracer.cu:112-122,155-187.
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+typedef float v16f_ __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float4 sload16_(const float4* base, uint32_t byte_off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) char* cptr1;
+    typedef const __attribute__((address_space(4))) v4f_* cptr4;
+    const v4f_ v = *(cptr4)((cptr1)(uintptr_t)base + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4*)((const char*)base + byte_off);
+#endif
+}
+__device__ __forceinline__ void sload64_(const float4* base, uint32_t byte_off, float4& q0, float4& q1, float4& q2, float4& q3)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) char* cptr1;
+    typedef const __attribute__((address_space(4))) v16f_* cptr16;
+    const v16f_ v = *(cptr16)((cptr1)(uintptr_t)base + byte_off);
+    q0 = make_float4(v.s0, v.s1, v.s2, v.s3); q1 = make_float4(v.s4, v.s5, v.s6, v.s7);
+    q2 = make_float4(v.s8, v.s9, v.sa, v.sb); q3 = make_float4(v.sc, v.sd, v.se, v.sf);
+#else
+    const float4* p = (const float4*)((const char*)base + byte_off);
+    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+#endif
+}
+__device__ __forceinline__ uint32_t uni_u32(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_primary_mesh_wave(const RenderArgs a)
+{
+    extern __shared__ uint32_t lds_stack[];
+    Cnt c;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* stk = lds_stack + wave * a.mstack_depth; // ONE stack per wave (entries are wave-uniform)
+    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    uint32_t px, py;
+    bool in_frame;
+    if (a.mode == 0) {
+        px = a.x0 + (blk % a.nbx) * 16u + lx;
+        py = a.y0 + (blk / a.nbx) * 16u + ly;
+        in_frame = (px < a.x1) && (py < a.y1);
+    } else {
+        const uint32_t per_tile = a.nbx * a.nby;
+        const uint32_t j = blk / per_tile, sub = blk % per_tile;
+        const uint32_t tile = a.first_tile + j * a.tile_stride;
+        px = (tile % a.tiles_x) * a.tile_w + (sub % a.nbx) * 16u + lx;
+        py = (tile / a.tiles_x) * a.tile_h + (sub / a.nbx) * 16u + ly;
+        in_frame = (px < a.p.width) && (py < a.p.height);
+    }
+    const f3 nU = mk3(-a.p.U[0], -a.p.U[1], -a.p.U[2]), nV = mk3(-a.p.V[0], -a.p.V[1], -a.p.V[2]);
+    const f3 W = mk3(a.p.W[0], a.p.W[1], a.p.W[2]);
+    const f3 eye = mk3(a.p.eye[0], a.p.eye[1], a.p.eye[2]);
+    f3 dir = mk3(0, 0, 0);
+    bool have_ray = in_frame;
+    if (in_frame) {
+        if (!a.p.mode_fisheye) get_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+        else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, dir);
+    }
+    if (COUNT && have_ray) c.rays++;
+    have_ray = have_ray && (length3(dir) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
+    MeshHit best{false, 0.f, 0.f, 0.f, 0u};
+    if (a.mroot != kNoRoot && __ballot(have_ray) != 0ull) { // (mesh_handle == 0 => miss)
+        const float tmin = kTraceMeshTmin;
+        float tmax = kTraceMeshTmax;
+        const rayinv ri = mk_rayinv(eye, dir);
+        uint32_t sp = 0, cur = a.mroot;
+        while (true) {
+            cur = uni_u32(cur);
+            if (cur & kLeafBit) {
+                const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t off = (first + j) * 48u;
+                    const float4 t0 = sload16_(a.tri, off), t1 = sload16_(a.tri, off + 16u), t2 = sload16_(a.tri, off + 32u);
+                    const uint32_t face = __float_as_uint(t0.w);
+                    float t, u, v;
+                    if (have_ray && tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), eye, dir, t, u, v)) {
+                        const bool inside = (t > tmin) && (t < tmax);
+                        const bool tie = best.hit && (t == best.t) && (face < best.face);
+                        if (inside || tie) {
+                            best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
+                            tmax = t;
+                        }
+                    }
+                }
+                if (sp == 0) break;
+                cur = stk[--sp];
+            } else {
+                float4 q0, q1, q2, q3;
+                sload64_(a.mnodes, cur << 6, q0, q1, q2, q3);
+                if (COUNT && have_ray) c.node_visits++;
+                float n0, f0, n1, f1;
+                box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
+                box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);
+                const bool h0 = have_ray && (n0 <= f0) && (f0 >= tmin) && (n0 <= tmax);
+                const bool h1 = have_ray && (n1 <= f1) && (f1 >= tmin) && (n1 <= tmax);
+                const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                if (m0 && m1) {
+                    // the nearer child first, as the first lane that wants any of them sees it
+                    const int l0 = (int)__builtin_ctzll(m0 | m1);
+                    const bool first0 = __shfl((int)((h0 && (!h1 || n0 <= n1)) ? 1 : 0), l0) != 0;
+                    if (lane == 0u) stk[sp] = first0 ? c1 : c0;
+                    sp++;
+                    cur = first0 ? c0 : c1;
+                } else if (m0) {
+                    cur = c0;
+                } else if (m1) {
+                    cur = c1;
+                } else {
+                    if (sp == 0) break;
+                    cur = stk[--sp];
+                }
+            }
+        }
+    }
+    int state = MeshPass;
+    float seg_tmax = a.p.t_max;
+    f3 normal = mk3(0, 0, 0), curO = mk3(0, 0, 0), curD = mk3(0, 0, 0);
+    uint32_t numBounces = 0;
+    if (have_ray) mesh_shade(a, best, eye, dir, state, seg_tmax, normal, curO, curD, numBounces);
     const size_t i = ((size_t)blk * kBlock + threadIdx.x) * 3;
     const uint32_t flags = (uint32_t)state | (numBounces << 8) | ((have_ray ? 1u : 0u) << 16);
     a.prec[i + 0] = make_float4(seg_tmax, __uint_as_float(flags), curO.x, curO.y);
@@ -541,7 +716,12 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             if (err) *err = std::string("wavefront setup: ") + hipGetErrorString(e);
             return GRT_ERR_HIP;
         }
-        hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
+        if (a.mesh_primary_wave && a.mstack_depth) { // one walk of the mesh tree per 8x8 tile instead of one per lane
+            auto fw = count ? k_primary_mesh_wave<true> : k_primary_mesh_wave<false>;
+            hipLaunchKernelGGL(fw, dim3(a.n_blocks), dim3(kBlock), sizeof(uint32_t) * 4u * a.mstack_depth, stream, a);
+        } else {
+            hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
+        }
         int rc = tile_kernel ? launch_render_tile(a, count, true, 0, stream, err) : launch_render_stream(a, count, true, stream, aux, err);
         if (rc != GRT_OK) return rc;
         RenderArgs b = a;
@@ -556,15 +736,37 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
         uint32_t in = 0, stage = 0;
         const uint32_t rounds = tile_kernel ? std::min<uint32_t>(a.bundle_rounds, (uint32_t)kMaxBundleRounds) : 0u;
         b.fcount = a.qcount + 2 * kMaxBundleRounds + 1;
+        const bool predict = tile_kernel && a.bverdict && a.qunit && a.qskip && a.heavy_a && aux && aux->aux && aux->fork && aux->join;
+        b.bverdict = nullptr; b.qunit = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
         for (uint32_t r = 0; r < rounds; r++) {
             b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
             b.queue = q[in ^ 1u]; b.qcount = a.qcount + stage + 1u;
             b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
             b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
+            const bool early = predict && r == 0; // bundle verdicts apply to the rays of the primary stage's tiles
+            if (early) { b.bverdict = a.bverdict; b.qunit = a.qunit; b.qskip = a.qskip; b.heavy_a = a.heavy_a; b.hcount_a = a.qcount + 3 * kMaxBundleRounds + 3; }
             hipLaunchKernelGGL(fq, dim3(qblocks), dim3(kBlock), lds, stream, b);
+            if (early) {
+                // the tiles known not to be bundles go one ray per wave BESIDE the bundle kernel: the bundles first (short waves, they take
+                // the machine and leave it within ~0.1 ms), the resident one-ray-per-wave grid on the second stream fills in behind them
+                if ((e = hipEventRecord(aux->fork, stream)) != hipSuccess || (e = hipStreamWaitEvent(aux->aux, aux->fork, 0)) != hipSuccess) {
+                    if (err) *err = std::string("wavefront pipeline: fork to the second stream: ") + hipGetErrorString(e);
+                    return GRT_ERR_HIP;
+                }
+            }
             rc = launch_render_tile(b, count, true, 1, stream, err);          // bundles; chunks over budget -> heavy list
-            if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err); // its rays: one per wave, to their end
+            if (rc == GRT_OK && early) {
+                RenderArgs s1 = b;
+                s1.heavy = a.heavy_a; s1.hcount = b.hcount_a; s1.hnext = a.qcount + 3 * kMaxBundleRounds + 4;
+                rc = launch_render_tile(s1, count, true, 2, aux->aux, err);   // the early list: one ray per wave, to their end
+                if (rc == GRT_OK && ((e = hipEventRecord(aux->join, aux->aux)) != hipSuccess || (e = hipStreamWaitEvent(stream, aux->join, 0)) != hipSuccess)) {
+                    if (err) *err = std::string("wavefront pipeline: join of the second stream: ") + hipGetErrorString(e);
+                    return GRT_ERR_HIP;
+                }
+            }
+            if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err); // the rays of the chunks that gave up now: one per wave, to their end
             if (rc != GRT_OK) return rc;
+            b.bverdict = nullptr; b.qunit = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
             in ^= 1u;
             stage++;
         }

@@ -354,16 +354,22 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
     (void)qstg;
     __shared__ uint32_t dstack[kStack]; // depth-first overflow: the batch that overflowed (<= 64) + kTileWide - 1 siblings
                                  // per wide level below it (tile_stack_fits, grt_internal.h)
+    bool first_draw = true;
     for (uint32_t unit_s = rank;;) { // (one trip; MODE 2: the waves draw the rays of the heavy list from a counter, so
                                      //  that a wave stuck with a long ray does not hold a share of the others back)
-    if (SINGLE) {
+    if (SINGLE && !first_draw) { // (a wave's FIRST ray is the one of its own number: 2816 atomics on one address at the start of every
+                                 //  launch took 30 us — an empty list's launch 34 us, and a mesh frame has three of those; the counter hands
+                                 //  out the rays behind the grid's)
         uint32_t u_ = 0;
         if (lane == 0u) u_ = atomicAdd(a.hnext, 1u);
-        unit_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)u_);
+        unit_s = gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)u_);
     }
+    first_draw = false;
     // (QUAD: wave i takes entry i of the list of four-way parts that k_quad_list compacted from the launch order, heaviest first; the
     //  grid is the list's capacity — no draw loop: a loop around the whole kernel keeps 75 scalar registers alive across it)
     if ((BUNDLE || QUAD) && unit_s >= n_in) break; // wave-uniform
+    // (a chunk whose tile gave up as a bundle in an earlier frame: its rays are on the early list of the one-ray-per-wave kernel already)
+    if (MODE == 1 && a.qskip && a.qskip[unit_s]) break;
     Cnt c, w;
     (void)w;
     // camera rays: an entry of the launch order may name a PART of a heavy tile (grt_internal.h: kOrderUnitMask; grt_bvh.hip:
@@ -1429,6 +1435,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         if (lane == 0) base = atomicAdd(a.hcount, (uint32_t)__popcll(vm));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (in_frame) a.heavy[base + lanes_below(vm)] = (uint32_t)ent;
+        if (a.bverdict && lane == 0) a.bverdict[a.qunit[unit_s]] = kBundleVerdictFrames; // the tile is no bundle: remembered (RenderArgs::bverdict)
         gave_up = true;
         break;
     }
@@ -1497,6 +1504,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
             if (lane == 0) base = atomicAdd(a.qcount, 1u);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             float4* q = a.queue + ((size_t)base * 64u + lane) * 4;
+            if (MODE == 0 && a.qunit && lane == 0) a.qunit[base] = ue & kOrderUnitMask; // whose chunk it is (bundle verdicts)
             if (cont) {
                 q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
                 q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);

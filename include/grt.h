@@ -219,7 +219,18 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            behind the LBVH build — what the reference asks OptiX for with PREFER_FAST_TRACE,
                                            src/GaussianTracer.cpp:360.  -1 (default): one sweep for trees that hold pieces of split proxies,
                                            none otherwise; 0: none; n (<= 8): n sweeps on any tree.  Levels and the reported height
-                                           (grt_bvh_info) are re-derived behind every sweep.  Culling structure only: same pixels */ };
+                                           (grt_bvh_info) are re-derived behind every sweep.  Culling structure only: same pixels */,
+       GRT_OPT_BUNDLE_PREDICT = 36      /* mesh frames on the tile kernel.  1 (default): an 8x8 tile whose bounced rays gave up as a bundle
+                                           (GRT_OPT_BUNDLE_BUDGET) is remembered; in the next frames its continuation rays go one per wave at
+                                           once, on a list that the one-ray-per-wave kernel works off BESIDE the bundle kernel (second
+                                           stream) instead of behind it, and the bundle that would be thrown away is not run.  A standing view
+                                           keeps its verdicts, a changing one uses each up in eight frames, a new scene / frame geometry starts
+                                           afresh.  0: every tile is tried as a bundle every frame (round 5).  Same rays through the same two
+                                           kernels: same pixels */,
+       GRT_OPT_MESH_PRIMARY_WAVE = 37   /* mesh frames, stage 1 (camera ray -> closest mesh hit, traceMesh of shaders/tracer.cuh:266-287).
+                                           1 (default): the 64 rays of an 8x8 tile walk the mesh tree TOGETHER (nodes and triangles by
+                                           scalar loads, a child is entered when any lane wants it, one stack per wave); 0: every lane walks
+                                           it alone (rounds 1-5).  The same hit records bit for bit */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -1,8 +1,10 @@
 """Every tuning option of the library is pure scheduling / data layout: frames must not change by a single byte."""
 import numpy as np
 import pytest
+import torch
 
 import grt
+import tiles
 from common import make_scene
 
 pytestmark = pytest.mark.gpu
@@ -373,3 +375,61 @@ def test_quad_parts_every_tile_under_window_overflow_sh_and_fisheye():
             assert (tr.render(pm)[0] == r8).all(), (j, it)
     tr.check()
     tr.close(); sc.close()
+
+
+@pytest.mark.parametrize("fisheye", [False, True], ids=["pinhole", "fisheye"])
+def test_mesh_primary_stage_per_tile_equals_per_lane(fisheye):
+    """GRT_OPT_MESH_PRIMARY_WAVE: stage 1 of a mesh frame (camera ray -> closest mesh hit -> closest-hit shading,
+    shaders/tracer.cuh:266-287, shaders/tracer.cu:155-187) with the 64 rays of an 8x8 tile walking the mesh tree together
+    (k_primary_mesh_wave) against every lane walking it alone (k_primary_mesh): MIRROR / NORMAL / GLASS, two meshes of which one is a
+    single triangle pair (a tree that is one leaf) and one a finely tessellated sphere seen at a grazing angle, a window launch, a tile
+    list, the streaming-kernel pipeline, hit counters — the same bytes, and the per-lane megakernel's."""
+    W, H = 200, 152
+    acts, p0, sc, op, center = make_scene(23, 15000, W, H, scale_boost=0.5)
+    sc.close()
+    eye = np.float32([0, 0, 3])
+    base = (0.25 * center + 0.75 * eye).astype(np.float32)
+    v1, n1, f1 = grt.sphere_mesh(base + np.float32([0.2, 0.05, 0]), tess_u=96, tess_v=48)
+    quad_v = np.float32([[-1.2, -0.9, -0.6], [0.1, -0.9, -0.4], [0.1, 0.4, -0.5], [-1.2, 0.4, -0.7]]) + center
+    quad_n = np.float32([[0.1, 0.0, 1.0], [-0.2, 0.1, 1.0], [0.0, -0.15, 1.0], [0.15, 0.1, 1.0]])
+    quad_n = (quad_n / np.linalg.norm(quad_n, axis=1, keepdims=True)).astype(np.float32)
+    meshes = [(v1, n1, f1), (quad_v, quad_n, np.uint32([[0, 1, 2], [0, 2, 3]]))]
+    for mesh_type in (grt.MIRROR, grt.NORMAL, grt.GLASS):
+        p = grt.default_params(W, H, center, mesh_type=mesh_type, max_bounces=4, fisheye=fisheye)
+        ref_t = grt.Tracer(0)
+        ref_t.set_option(grt.OPT_KERNEL, 1)
+        ref_t.upload(acts)
+        ref_t.set_meshes(meshes)
+        ref8, reff = ref_t.render(p, want_f32=True)
+        ref_t.close()
+        for kernel in (0, 3):
+            t = grt.Tracer(0)
+            t.set_option(grt.OPT_KERNEL, kernel)
+            t.upload(acts)
+            t.set_meshes(meshes)
+            t.set_option(grt.OPT_COUNTERS, 1)
+            cnts = {}
+            for wave in (0, 1):
+                t.set_option(grt.OPT_MESH_PRIMARY_WAVE, wave)
+                for _ in range(2):
+                    a8, af = t.render(p, want_f32=True)
+                    assert bool((a8 == ref8).all()) and bool((af == reff).all()), (mesh_type, kernel, wave)
+                c = t.counters()
+                cnts[wave] = (c["rays"], c["segments"], c["hit_evals"])
+                assert c["stall_exits"] == 0
+                # a window and a tile list of the same frame
+                w8 = torch.zeros_like(ref8); wf = torch.zeros_like(reff)
+                t.render(p, window=(40, 24, 168, 120), out_u8=w8, out_f32=wf)
+                assert bool((w8[24:120, 40:168] == ref8[24:120, 40:168]).all()) and bool((wf[24:120, 40:168] == reff[24:120, 40:168]).all())
+                tx, ty = tiles.grid(W, H, 32)
+                _, _, cnt_t, max_cnt = tiles.my_tiles(tx * ty, 2, 1)
+                buf = torch.zeros((max_cnt, 32, 32, 3), dtype=torch.uint8, device="cuda:0")
+                t.render_tiles(p, 32, 32, 1, 2, cnt_t, out_u8=buf)
+                full = tiles.assemble([torch.zeros_like(buf), buf], W, H, 32)
+                for j in range(cnt_t):
+                    k = 1 + 2 * j
+                    y0, x0 = (k // tx) * 32, (k % tx) * 32
+                    assert bool((full[y0:y0 + 32, x0:x0 + 32] == ref8[y0:y0 + 32, x0:x0 + 32]).all()), (mesh_type, kernel, wave, k)
+            assert cnts[0] == cnts[1]
+            t.check()
+            t.close()

@@ -510,17 +510,40 @@ def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
               "every ray retried alone (own mesh trace)": (0, 1024, 1), "all alone": (2, 1, 128), "default": (2, 1024, 128),
               "deep": (4, 24, 16), "one round": (1, 64, 128)}
     segs = set()
+    # (round 6: bundle verdicts, GRT_OPT_BUNDLE_PREDICT — a tile whose bounced rays gave up as a bundle sends them one per wave at
+    #  once in the following frames, beside the bundle kernel on a second stream.  Every route runs with verdicts off (one frame: round
+    #  5's pipeline) and on (three frames of a standing view: the first gives the verdicts, the next two use them), and under a view
+    #  that changes every frame — a verdict is then used up in eight frames and the tile is tried as a bundle again)
     for name, (rounds, budget, lane_budget) in routes.items():
-        t.set_option(grt.OPT_BUNDLE_ROUNDS, rounds)
-        t.set_option(grt.OPT_BUNDLE_BUDGET, budget)
-        t.set_option(grt.OPT_LANE_BUDGET, lane_budget)
-        u8, f32 = t.render(p, want_f32=True)
-        cnt = t.counters()
-        assert bool((u8 == ref_u8).all()), name
-        assert bool((f32 == ref_f32).all()), name
-        assert cnt["stall_exits"] == 0, name
-        segs.add((cnt["segments"], cnt["hit_evals"]))
+        for predict, n_frames in ((0, 1), (1, 3)):
+            t.set_option(grt.OPT_BUNDLE_PREDICT, predict)
+            t.set_option(grt.OPT_BUNDLE_ROUNDS, rounds)
+            t.set_option(grt.OPT_BUNDLE_BUDGET, budget)
+            t.set_option(grt.OPT_LANE_BUDGET, lane_budget)
+            for k in range(n_frames):
+                u8, f32 = t.render(p, want_f32=True)
+                cnt = t.counters()
+                assert bool((u8 == ref_u8).all()), (name, predict, k)
+                assert bool((f32 == ref_f32).all()), (name, predict, k)
+                assert cnt["stall_exits"] == 0, (name, predict, k)
+                segs.add((cnt["segments"], cnt["hit_evals"]))
     assert len(segs) == 1  # the same segments and the same composited events on every route
+    if sh_degree == 0:
+        # a view that changes every frame (the eye wobbles, 12 frames: verdicts given, used, used up, given again): each frame equals
+        # the per-lane megakernel's frame of the same view
+        t.set_option(grt.OPT_BUNDLE_ROUNDS, 2); t.set_option(grt.OPT_BUNDLE_BUDGET, 48); t.set_option(grt.OPT_LANE_BUDGET, 128)
+        ref_t = grt.Tracer(0)
+        ref_t.set_option(grt.OPT_KERNEL, 1)
+        ref_t.upload(acts)
+        ref_t.set_meshes(meshes)
+        for k in range(12):
+            q = grt.default_params(192, 160, center, mesh_type=mesh_type, max_bounces=8, sh_degree=sh_degree,
+                                   eye=(0.02 * (k % 3), 0.01 * (k % 2), 3.0))
+            u8, f32 = t.render(q, want_f32=True)
+            r8, rf = ref_t.render(q, want_f32=True)
+            assert bool((u8 == r8).all()) and bool((f32 == rf).all()), ("moving view", k)
+        t.check()
+        ref_t.close()
     with pytest.raises(grt.GrtError):
         t.set_option(grt.OPT_BUNDLE_ROUNDS, 5)
     t.close()
