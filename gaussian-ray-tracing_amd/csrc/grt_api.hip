@@ -624,7 +624,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     }
     else if (option == GRT_OPT_BUNDLE_BUDGET) { c->opt_bundle_budget = std::max(1, value); c->bv_epoch = ~0ull; /* (a verdict is a statement about THIS budget) */ }
     else if (option == GRT_OPT_LANE_BUDGET) { c->opt_lane_budget = std::max(1, value); }
-    else if (option == GRT_OPT_MESH_PRIMARY_WAVE) { c->opt_mesh_primary_wave = value ? 1 : 0; }
+    else if (option == GRT_OPT_MESH_PRIMARY_WAVE) { c->opt_mesh_primary_wave = value < 0 ? 0 : (value > 2 ? 2 : value); }
     else if (option == GRT_OPT_BUNDLE_PREDICT) { c->opt_bundle_predict = value ? 1 : 0; c->bv_epoch = ~0ull; /* (verdicts start afresh) */ }
     else if (option == GRT_OPT_SINGLE_LOOKAHEAD) { c->opt_single_look = std::max(0, value); }
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
@@ -1481,8 +1481,10 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
     a.bundle_budget = (uint32_t)c->opt_bundle_budget * (a.p.type == GRT_GLASS ? 2u : 1u);
     a.lane_budget = (uint32_t)c->opt_lane_budget;
     a.single_own_mesh = 0;
-    a.mesh_primary_wave = c->opt_mesh_primary_wave ? 1u : 0u;
     a.mstack_depth = sc->mbvh.height + 2u;
+    // (2 = fused into the tile kernel's primary stage, on its depth-first stack: only when the mesh tree's walk fits it)
+    a.mesh_primary_wave = (uint32_t)c->opt_mesh_primary_wave;
+    if (a.mesh_primary_wave == 2u && a.mstack_depth > kTileStack) a.mesh_primary_wave = 1u;
     a.single_look = (float)c->opt_single_look / 1024.0f;
     a.single_band = (float)c->opt_single_band / 1024.0f;
     if (sc->n_faces && a.mode != 2) { // mesh frame: buffers of the wavefront pipeline (one record per launched thread)

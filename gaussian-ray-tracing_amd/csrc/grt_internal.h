@@ -377,7 +377,7 @@ struct grt_ctx {
     int opt_bundle_budget = 1400; // (round 6, with bundle verdicts: C4 2.55 ms at 896, 2.48 at 1100, 2.42 at 1300, 2.40 at 1400-1500, 2.46 at 1700; a glass sphere 4.8 / 4.4 / 4.3 / 4.4 at 896 / 1300 / 1400 / 1500 — the bundles run BESIDE the one-ray-per-wave kernel now, so a longer bundle costs nothing until it outlasts that kernel; round 3 without verdicts: 896, profiles/tools/tune_c4.py)
     int opt_lane_budget = 128;
     int opt_bundle_predict = 1; // GRT_OPT_BUNDLE_PREDICT
-    int opt_mesh_primary_wave = 1; // GRT_OPT_MESH_PRIMARY_WAVE
+    int opt_mesh_primary_wave = 2; // GRT_OPT_MESH_PRIMARY_WAVE (C4: 2.40 / 2.30 / 2.24 ms at 0 / 1 / 2)
     int opt_single_look = 256, opt_single_band = 256; // 1/1024
     uint32_t* d_heavy = nullptr;
     float4* d_fqueue = nullptr;

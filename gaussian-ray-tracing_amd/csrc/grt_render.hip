@@ -397,41 +397,6 @@ __global__ __launch_bounds__(kBlock) void k_primary_mesh(const RenderArgs a)
 // order, and (t, u, v) come from the same arithmetic on the same triangle: the SAME record, bit for bit
 // (tests/test_gpu_parity.py: every mesh test runs both kernels).  Reference: traceMesh + __closesthit__ / __miss__,
 // shaders/tracer.cuh:266-287, shaders/tracer.cu:112-122,155-187.
-typedef float v4f_ __attribute__((ext_vector_type(4)));
-typedef float v16f_ __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ float4 sload16_(const float4* base, uint32_t byte_off)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) char* cptr1;
-    typedef const __attribute__((address_space(4))) v4f_* cptr4;
-    const v4f_ v = *(cptr4)((cptr1)(uintptr_t)base + byte_off);
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *(const float4*)((const char*)base + byte_off);
-#endif
-}
-__device__ __forceinline__ void sload64_(const float4* base, uint32_t byte_off, float4& q0, float4& q1, float4& q2, float4& q3)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) char* cptr1;
-    typedef const __attribute__((address_space(4))) v16f_* cptr16;
-    const v16f_ v = *(cptr16)((cptr1)(uintptr_t)base + byte_off);
-    q0 = make_float4(v.s0, v.s1, v.s2, v.s3); q1 = make_float4(v.s4, v.s5, v.s6, v.s7);
-    q2 = make_float4(v.s8, v.s9, v.sa, v.sb); q3 = make_float4(v.sc, v.sd, v.se, v.sf);
-#else
-    const float4* p = (const float4*)((const char*)base + byte_off);
-    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-#endif
-}
-__device__ __forceinline__ uint32_t uni_u32(uint32_t v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-#else
-    return v;
-#endif
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_primary_mesh_wave(const RenderArgs a)
 {
@@ -466,61 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_mesh_wave(const RenderArgs a
     }
     if (COUNT && have_ray) c.rays++;
     have_ray = have_ray && (length3(dir) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
-    MeshHit best{false, 0.f, 0.f, 0.f, 0u};
-    if (a.mroot != kNoRoot && __ballot(have_ray) != 0ull) { // (mesh_handle == 0 => miss)
-        const float tmin = kTraceMeshTmin;
-        float tmax = kTraceMeshTmax;
-        const rayinv ri = mk_rayinv(eye, dir);
-        uint32_t sp = 0, cur = a.mroot;
-        while (true) {
-            cur = uni_u32(cur);
-            if (cur & kLeafBit) {
-                const uint32_t first = leaf_first(cur), cnt = leaf_count(cur);
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const uint32_t off = (first + j) * 48u;
-                    const float4 t0 = sload16_(a.tri, off), t1 = sload16_(a.tri, off + 16u), t2 = sload16_(a.tri, off + 32u);
-                    const uint32_t face = __float_as_uint(t0.w);
-                    float t, u, v;
-                    if (have_ray && tri_hit(mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), eye, dir, t, u, v)) {
-                        const bool inside = (t > tmin) && (t < tmax);
-                        const bool tie = best.hit && (t == best.t) && (face < best.face);
-                        if (inside || tie) {
-                            best.hit = true; best.t = t; best.u = u; best.v = v; best.face = face;
-                            tmax = t;
-                        }
-                    }
-                }
-                if (sp == 0) break;
-                cur = stk[--sp];
-            } else {
-                float4 q0, q1, q2, q3;
-                sload64_(a.mnodes, cur << 6, q0, q1, q2, q3);
-                if (COUNT && have_ray) c.node_visits++;
-                float n0, f0, n1, f1;
-                box_interval(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ri, n0, f0);
-                box_interval(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ri, n1, f1);
-                const bool h0 = have_ray && (n0 <= f0) && (f0 >= tmin) && (n0 <= tmax);
-                const bool h1 = have_ray && (n1 <= f1) && (f1 >= tmin) && (n1 <= tmax);
-                const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-                const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                if (m0 && m1) {
-                    // the nearer child first, as the first lane that wants any of them sees it
-                    const int l0 = (int)__builtin_ctzll(m0 | m1);
-                    const bool first0 = __shfl((int)((h0 && (!h1 || n0 <= n1)) ? 1 : 0), l0) != 0;
-                    if (lane == 0u) stk[sp] = first0 ? c1 : c0;
-                    sp++;
-                    cur = first0 ? c0 : c1;
-                } else if (m0) {
-                    cur = c0;
-                } else if (m1) {
-                    cur = c1;
-                } else {
-                    if (sp == 0) break;
-                    cur = stk[--sp];
-                }
-            }
-        }
-    }
+    const MeshHit best = mesh_closest_wave<COUNT>(a, stk, have_ray, eye, dir, kTraceMeshTmin, kTraceMeshTmax, c.node_visits);
     int state = MeshPass;
     float seg_tmax = a.p.t_max;
     f3 normal = mk3(0, 0, 0), curO = mk3(0, 0, 0), curD = mk3(0, 0, 0);
@@ -716,7 +627,9 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             if (err) *err = std::string("wavefront setup: ") + hipGetErrorString(e);
             return GRT_ERR_HIP;
         }
-        if (a.mesh_primary_wave && a.mstack_depth) { // one walk of the mesh tree per 8x8 tile instead of one per lane
+        if (tile_kernel && a.mesh_primary_wave == 2u) {
+            // stage 1 runs inside stage 2 (grt_render_tile.hip, MODE 0 with MESH): no launch here
+        } else if (a.mesh_primary_wave && a.mstack_depth) { // one walk of the mesh tree per 8x8 tile instead of one per lane
             auto fw = count ? k_primary_mesh_wave<true> : k_primary_mesh_wave<false>;
             hipLaunchKernelGGL(fw, dim3(a.n_blocks), dim3(kBlock), sizeof(uint32_t) * 4u * a.mstack_depth, stream, a);
         } else {

@@ -322,6 +322,24 @@ __device__ __forceinline__ void bag_prune(float4* bp, bool doit, uint32_t& nb, u
 // the lane's first pending event lies in its cell, and the repeats that are still possible are dropped.  Scenes without
 // pieces run the PIECES = false instantiation, whose code is what it was before pieces existed (the few extra
 // instructions cost the default scene 1.3 %, and any change to this kernel's hot loop is a lottery: see the watchdog).
+// stage 1 of a mesh frame for the wave's 64 camera rays (k_primary_mesh_wave's work, record layout and all), called from the
+// primary stage of the tile kernel when the two are fused (RenderArgs::mesh_primary_wave == 2)
+template <bool COUNT>
+__device__ __forceinline__ void mesh_primary_fused(const RenderArgs& a, uint32_t* stk, bool have_ray, f3 o, f3 d, float4& r0, float4& r1,
+                                                             float4& r2, uint32_t& nv)
+{
+    const MeshHit mh = mesh_closest_wave<COUNT>(a, stk, have_ray, o, d, kTraceMeshTmin, kTraceMeshTmax, nv);
+    int st_ = MeshPass;
+    uint32_t nb_ = 0;
+    float seg_tmax = a.p.t_max;
+    f3 nrm_ = mk3(0, 0, 0), nextO = mk3(0, 0, 0), nextD = mk3(0, 0, 0);
+    if (have_ray) mesh_shade(a, mh, o, d, st_, seg_tmax, nrm_, nextO, nextD, nb_);
+    const uint32_t flags = (uint32_t)st_ | (nb_ << 8) | ((have_ray ? 1u : 0u) << 16);
+    r0 = make_float4(seg_tmax, __uint_as_float(flags), nextO.x, nextO.y);
+    r1 = make_float4(nextO.z, nextD.x, nextD.y, nextD.z);
+    r2 = make_float4(nrm_.x, nrm_.y, nrm_.z, 0.0f);
+}
+
 template <bool COUNT, bool SH, bool MESH, int MODE, bool PIECES>
 __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWavesQuad : kWavesPerSimd)) void k_render_tile(const RenderArgs a)
 {
@@ -438,7 +456,8 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         else have_ray = get_fisheye_ray(px, py, nU, nV, W, a.p.width, a.p.height, d);
     }
     have_ray = have_ray && GRT_IN_PART;
-    if (COUNT && have_ray && !MESH && tally) c.rays++;
+    // (mesh frames: stage 1 counts the rays — unless this kernel IS stage 1: a.mesh_primary_wave == 2, below)
+    if (COUNT && have_ray && tally && (!MESH || (MODE == 0 && a.mesh_primary_wave == 2u))) c.rays++;
     have_ray = have_ray && (length3(d) > 0.1f) && (a.p.max_bounces > 0u); // loop guard, shaders/tracer.cu:59
     float seg_tmax = a.p.t_max;
     uint32_t pflags = 0;
@@ -455,6 +474,23 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
             hitN = nrm_;
             pflags = (uint32_t)st_ | (nb_ << 8) | (1u << 16);
         }
+    } else if (MESH && MODE == 0 && a.mesh_primary_wave == 2u) {
+        // stage 1 FUSED (round 6): the tile's 64 camera rays walk the mesh tree together right here (grt_mesh.h: mesh_closest_wave, on
+        // the depth-first stack, idle before the first pass) — no launch of its own in front of the Gaussian stage (0.16 ms of a 2.3 ms
+        // frame, its long waves those of the sphere's limb), no 48-B record per pixel written and read back.  The same MeshHit and
+        // closest-hit shading as k_primary_mesh, bit for bit.
+        // (inlined.  As a function of its own — __attribute__((noinline)), tried — the CALL costs every launch of this kernel its scratch
+        //  set-up and C4 went from 2.29 to 3.0 ms whichever stage-1 form ran; inlined it costs this instantiation 63 more spilled VGPRs
+        //  outside the loops and 21 more lane moves inside them, and the frame still gains: 2.29 -> 2.24 ms)
+        float4 r0_, r1_, r2_;
+        uint32_t nv_ = 0;
+        mesh_primary_fused<COUNT>(a, dstack, have_ray, o, d, r0_, r1_, r2_, nv_);
+        if (COUNT) c.node_visits += nv_;
+        seg_tmax = r0_.x;
+        pflags = __float_as_uint(r0_.y);
+        nextO = mk3(r0_.z, r0_.w, r1_.x);
+        nextD = mk3(r1_.y, r1_.z, r1_.w);
+        hitN = mk3(r2_.x, r2_.y, r2_.z);
     } else if (MESH) { // stage 1 (k_primary_mesh / k_queue_mesh) already traced the mesh for this ray
         const size_t pi = BUNDLE ? ent * 3 : ((size_t)blk * kBlock + wave * 64u + lane) * 3;
         const float4 pr0 = a.prec[pi], pr1 = a.prec[pi + 1], pr2 = a.prec[pi + 2];

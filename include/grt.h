@@ -227,10 +227,13 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            keeps its verdicts, a changing one uses each up in eight frames, a new scene / frame geometry starts
                                            afresh.  0: every tile is tried as a bundle every frame (round 5).  Same rays through the same two
                                            kernels: same pixels */,
-       GRT_OPT_MESH_PRIMARY_WAVE = 37   /* mesh frames, stage 1 (camera ray -> closest mesh hit, traceMesh of shaders/tracer.cuh:266-287).
-                                           1 (default): the 64 rays of an 8x8 tile walk the mesh tree TOGETHER (nodes and triangles by
-                                           scalar loads, a child is entered when any lane wants it, one stack per wave); 0: every lane walks
-                                           it alone (rounds 1-5).  The same hit records bit for bit */ };
+       GRT_OPT_MESH_PRIMARY_WAVE = 37   /* mesh frames, stage 1 (camera ray -> closest mesh hit -> closest-hit shading: traceMesh of
+                                           shaders/tracer.cuh:266-287, shaders/tracer.cu:112-122,155-187).  0: every lane walks the mesh
+                                           tree alone, in a kernel of its own in front of the Gaussian stage (rounds 1-5); 1: the 64 rays
+                                           of an 8x8 tile walk it TOGETHER (nodes and triangles by scalar loads, a child is entered when
+                                           any lane wants it, one stack per wave), still a kernel of its own; 2 (default): that walk runs
+                                           at the head of the tile kernel's primary stage — no launch, no 48-B record per pixel (other
+                                           pipelines, and mesh trees too deep for the tile kernel's stack: as 1).  Every lane walks it alone (rounds 1-5).  The same hit records bit for bit */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -90,7 +90,9 @@ def kernels_of(path):
     while i < len(L):
         m = re.match(r"^(_Z\w+):", L[i])
         if m and m.group(1) in meta:
-            e = next(k for k in range(i, len(L)) if L[k].strip().startswith("s_endpgm"))
+            # (to the end of the FUNCTION, not to its first s_endpgm: a kernel with an early exit — the bundle kernel's skip of a chunk
+            #  on the early list, round 6 — has several)
+            e = next(k for k in range(i, len(L)) if L[k].startswith(".Lfunc_end")) - 1
             out[m.group(1)] = (meta[m.group(1)], L[i + 1:e + 1])
             i = e
         i += 1

@@ -409,7 +409,7 @@ def test_mesh_primary_stage_per_tile_equals_per_lane(fisheye):
             t.set_meshes(meshes)
             t.set_option(grt.OPT_COUNTERS, 1)
             cnts = {}
-            for wave in (0, 1):
+            for wave in (0, 1, 2):
                 t.set_option(grt.OPT_MESH_PRIMARY_WAVE, wave)
                 for _ in range(2):
                     a8, af = t.render(p, want_f32=True)
@@ -430,6 +430,6 @@ def test_mesh_primary_stage_per_tile_equals_per_lane(fisheye):
                     k = 1 + 2 * j
                     y0, x0 = (k // tx) * 32, (k % tx) * 32
                     assert bool((full[y0:y0 + 32, x0:x0 + 32] == ref8[y0:y0 + 32, x0:x0 + 32]).all()), (mesh_type, kernel, wave, k)
-            assert cnts[0] == cnts[1]
+            assert cnts[0] == cnts[1] == cnts[2]
             t.check()
             t.close()
