@@ -46,6 +46,8 @@ WORKLOADS = {
     "C3": (3, 1_000_000, 1920, 1080, False, False, 32, 0.0),
     # C3 with trained-scene-like anisotropy: every axis' log-scale gets N(0, 1.6^2) on top (needles, pancakes)
     "C3a": (3, 1_000_000, 1920, 1080, False, False, 32, 1.6),
+    # ... and the middle point: sigma 1.0 — a trained scene's scales are closer to this than to C3's 0.5 alone
+    "C3b": (3, 1_000_000, 1920, 1080, False, False, 32, 1.0),
     "C4": (3, 1_000_000, 1920, 1080, False, True, 2, 0.0),
     "C5": (5, 3_000_000, 3840, 2160, True, False, 32, 0.0),
 }
@@ -53,6 +55,7 @@ TILE = 32  # screen tiles dealt round-robin to the ranks (--tile: any multiple o
            # keep neighbouring 8x8 wave tiles — which share BVH nodes and records — on one GPU)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 TRAFFIC_FILE = os.path.join("profiles", "traffic.json")
+ROUND = "r06"  # `roofline.traffic` is printed only from counters collected in THIS round for THIS kernel (profiles/collect.sh tags its entries)
 
 
 def kernel_name(variant, with_mesh, sh_degree, leaf_max=4, pieces=False):
@@ -437,17 +440,25 @@ def main():
         b_fetch = algorithmic_bytes(cnt, pix_mine, args.sh_degree)  # as fetched (records are shared by a wave: below the floor)
         b_min = cnt["hit_evals"] * (44 + 12 * (args.sh_degree + 1) ** 2) + pix_mine * 3  # SURVEY §8(d) floor
         achieved = b_alg / (kernel_ms * 1e-3) / 1e9
-        traffic = valu = traffic_source = None
+        traffic = valu = traffic_source = traffic_round = None
+        kname = kernel_name(args.kernel, with_mesh, args.sh_degree, pieces=info["n_primitives"] > info["n_proxies"])
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.workload}_sh{args.sh_degree}_k{args.kernel}_n{t_world}"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                valu = tj.get(key, {}).get("valu")  # SQ counters of the same launch: what actually bounds the kernel
-                if traffic is not None or valu is not None:
-                    traffic_source = (f"{TRAFFIC_FILE} ['{key}']: rocprofv3 --pmc passes of this same command collected by "
-                                      f"profiles/collect.sh ({tj.get(key, {}).get('collected', 'date not recorded')}); NOT measured by this run")
+                ent = tj.get(key, {})
+                traffic_round = ent.get("round")
+                #  counters of another round's build, or of another kernel, are not this build's traffic: not printed
+                if ent and traffic_round == ROUND and ent.get("kernel") == kname:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    valu = ent.get("valu")  # SQ counters of the same launch: what actually bounds the kernel
+                    if traffic is not None or valu is not None:
+                        traffic_source = (f"{TRAFFIC_FILE} ['{key}']: rocprofv3 --pmc passes of this same command collected by "
+                                          f"profiles/collect.sh in round {traffic_round} ({ent.get('collected', 'date not recorded')}); NOT measured by this run")
+                elif ent:
+                    traffic_source = (f"{TRAFFIC_FILE} ['{key}'] holds counters of round {traffic_round} for kernel {ent.get('kernel')}: not this "
+                                      f"round's ({ROUND}) / this kernel ({kname}); traffic not printed")
             except Exception:
                 traffic = None
         out = {
@@ -500,7 +511,8 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name(args.kernel, with_mesh, args.sh_degree, pieces=info["n_primitives"] > info["n_proxies"]), "algorithmic_bytes_per_launch": int(b_alg),
+                         "traffic_collected_round": traffic_round,
+                         "kernel": kname, "algorithmic_bytes_per_launch": int(b_alg),
                          "formula": "SURVEY 8(d): H * (44 + 12 (deg + 1)^2) + V * 32 + P * 3, H = consumed hit evaluations, V = child boxes tested, "
                                     "P = pixels; / kernel_ms (HIP events on the launch stream) / 8 TB/s",
                          "floor_bytes_per_launch": int(b_min),

@@ -517,8 +517,11 @@ int grt_create_view(grt_ctx* parent, grt_ctx** out)
     const int rc = grt_create(&v, parent->device);
     if (rc != GRT_OK) return rc;
     v->parent = parent;
-    parent->n_views++;
-    parent->views.push_back(v);
+    {
+        std::lock_guard<std::mutex> lk(parent->views_mu);
+        parent->n_views++;
+        parent->views.push_back(v);
+    }
     *out = v;
     return GRT_OK;
 }
@@ -585,9 +588,14 @@ void grt_destroy(grt_ctx* c)
     (void)hipDeviceSynchronize(); // renders of this slot (and, for a scene, of its views) may be in flight on any stream
     if (c->parent) {
         grt_ctx* p = c->parent;
-        p->views.erase(std::remove(p->views.begin(), p->views.end(), c), p->views.end());
+        bool last;
+        {   // (a sibling's launch may be looking at this view's frame-end event: off the list first, under the lock, then destroyed)
+            std::lock_guard<std::mutex> lk(p->views_mu);
+            p->views.erase(std::remove(p->views.begin(), p->views.end(), c), p->views.end());
+            last = --p->n_views == 0;
+        }
         destroy_now(c);
-        if (--p->n_views == 0 && p->zombie) destroy_now(p);
+        if (last && p->zombie) destroy_now(p);
         return;
     }
     if (c->n_views > 0) { c->zombie = true; return; } // its views still render this scene
@@ -1115,7 +1123,8 @@ static uint32_t parts_extra_cap(uint32_t n_units)
 // is a frame of another slot of this scene still running?  (its frame-end event, recorded on its stream behind its last kernels)
 static bool sibling_frames_in_flight(const grt_ctx* c)
 {
-    const grt_ctx* sc = scene_of(c);
+    grt_ctx* sc = const_cast<grt_ctx*>(scene_of(c));
+    std::lock_guard<std::mutex> lk(sc->views_mu); // (views come and go on other threads: grt_create_view / grt_destroy take the same lock)
     if (sc->n_views == 0) return false;
     auto busy = [&](const grt_ctx* s) { return s != c && s->have_timing && s->ev1 && hipEventQuery(s->ev1) == hipErrorNotReady; };
     if (busy(sc)) return true;

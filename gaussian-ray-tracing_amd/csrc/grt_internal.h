@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/grt.h"
@@ -259,6 +260,8 @@ struct grt_ctx {
     grt_ctx* parent = nullptr; // view: the context whose scene this one renders
     int n_views = 0;           // live views of this context
     std::vector<grt_ctx*> views; // ... and which (a scene's frame slots look at each other's frame-end events: are frames in flight?)
+    std::mutex views_mu;         // guards `views` / `n_views` and the siblings' frame-end events while they are looked at: views are contexts,
+                                 // and grt.h lets distinct contexts be driven from distinct threads
     bool zombie = false;       // destroyed while views were alive: freed with the last of them
     uint64_t seen_epoch = 0;   // scene_epoch of the scene at this slot's last launch
     int device = 0;

@@ -7,7 +7,7 @@ TAG=${1:-rXX}
 O=gpurun_out/all_$TAG
 mkdir -p $O
 python3 bench.py > $O/C3.json 2> $O/C3.err
-for w in C1 C2 C3a C4 C5; do python3 bench.py --no-cpu-baseline --workload $w > $O/$w.json 2> $O/$w.err; echo "$w done"; done
+for w in C1 C2 C3a C3b C4 C5; do python3 bench.py --no-cpu-baseline --workload $w > $O/$w.json 2> $O/$w.err; echo "$w done"; done
 python3 bench.py --no-cpu-baseline --sh-degree 3 > $O/C3_sh3.json 2> $O/C3_sh3.err
 python3 bench.py --no-cpu-baseline --kernel 3 --no-extra-legs > $O/C3_stream_kernel.json 2> $O/C3_stream_kernel.err
 for n in 2 4 8; do python3 bench.py --no-cpu-baseline --emulate-ranks $n > $O/C3_emulated_rank_of_$n.json 2> $O/C3_emulated_rank_of_$n.err; echo "ranks $n done"; done

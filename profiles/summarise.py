@@ -5,6 +5,7 @@ bench.py runs first is skipped: only dispatches after the first 2 are used)."""
 import csv, datetime, glob, json, os, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
+ROUND = tag.split("_")[0]  # "r06" of "r06", "r06pre", "r06_C4" ...: the round the counters were collected in (bench.py checks it)
 wl = sys.argv[3] if len(sys.argv) > 3 else "C3"
 label = sys.argv[4] if len(sys.argv) > 4 else ""
 here = os.path.dirname(os.path.abspath(__file__))
@@ -19,7 +20,7 @@ for line in open(src + "/bench_under_rocprof.log"):
 # the dominant kernel is the one the bench line names (tile kernel: <COUNT, SH, MESH, MODE, PIECES>)
 KERNEL = bench_line["roofline"]["kernel"].replace("grt::", "") if bench_line else "k_render_tile<false, false, false, 0, false>"
 # mesh frames: the stages of the wavefront pipeline are kernels of their own
-STAGES = ["k_primary_mesh<false>", "k_render_tile<false, false, true, 0,", "k_queue_mesh<false>", "k_render_tile<false, false, true, 1,",
+STAGES = ["k_primary_mesh<false>", "k_primary_mesh_wave<false>", "k_render_tile<false, false, true, 0,", "k_queue_mesh<false>", "k_render_tile<false, false, true, 1,",
           "k_render_tile<false, false, true, 2,", "k_bounce<false>"] if "true, 0" in KERNEL else []
 
 for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
@@ -139,6 +140,6 @@ tpath = os.path.join(here, "traffic.json")
 tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
 sh_deg = 3 if label == "sh3" else 0
 tj[f"{wl}_sh{sh_deg}_k0_n1"] = {"hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "valu": res.get("valu"), "collected": res["collected"],
-                      "kernel": res["kernel"], "source": f"profiles/{tag}_counters.json"}
+                      "round": ROUND, "kernel": res["kernel"], "source": f"profiles/{tag}_counters.json"}
 json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(res, indent=1))
