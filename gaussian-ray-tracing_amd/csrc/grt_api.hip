@@ -614,7 +614,8 @@ int grt_set_option(grt_ctx* c, int option, int value)
         c->opt_kernel = value;
         c->cost_valid = false; // scheduling units differ between kernels
     }
-    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : ((value & 2) ? 0 : 2); c->cost_valid = false; }
+    else if (option == GRT_OPT_FEEDBACK) { c->opt_feedback = value ? 1 : 0; c->opt_heavy_split = (value & 4) ? 1 : ((value & 2) ? 0 : 2); c->cost_valid = false;
+                                             c->bv_epoch = ~0ull; /* (what the frames before taught — costs, and the bundle verdicts of mesh frames — is forgotten) */ }
     else if (option == GRT_OPT_HEAVY_THRESHOLD_X2) { c->opt_heavy_thr_x2 = std::max(2, value); }
     else if (option == GRT_OPT_HEAVY_CAP_DIV) { c->opt_heavy_cap_div = std::max(1, value); }
     else if (option == GRT_OPT_SWIZZLE) {
@@ -1518,7 +1519,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.queue_alt = c->d_queue + c->wf_cap * 4;
         a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
-    a.bverdict = nullptr; a.qunit = nullptr; a.qskip = nullptr; a.heavy_a = nullptr; a.hcount_a = nullptr; a.bverdict_decay = 0;
+    a.bverdict = nullptr; a.qunit = nullptr; a.qskip = nullptr; a.heavy_a = nullptr; a.hcount_a = nullptr; a.bverdict_epoch = 0;
     const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max, sc->gbvh.n_prims);
     if (sc->n_faces && a.mode != 2 && tile_kernel && c->opt_bundle_predict && c->opt_bundle_rounds > 0 && c->wf_cap) {
         // bundle verdicts (RenderArgs::bverdict): one word per 8x8 tile of the launch; they belong to a launch geometry and a scene —
@@ -1547,7 +1548,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
             c->bv_params_valid = false;
         }
         a.bverdict = c->d_bverdict; a.qunit = c->d_qunit; a.qskip = c->d_qskip; a.heavy_a = c->d_heavy_a;
-        a.bverdict_decay = (c->bv_params_valid && memcmp(&c->bv_params, &a.p, sizeof(grt_params)) == 0) ? 0u : 1u;
+        if (!(c->bv_params_valid && memcmp(&c->bv_params, &a.p, sizeof(grt_params)) == 0)) c->bv_view = (c->bv_view + 1u) ? c->bv_view + 1u : 1u; // another view (never 0: a cleared word is no verdict)
+        a.bverdict_epoch = c->bv_view;
         c->bv_params = a.p;
         c->bv_params_valid = true;
     }

@@ -156,7 +156,11 @@ struct RenderArgs {
     uint32_t* qskip;          // [chunks] 1 = the chunk's rays are on the early list: the bundle kernel leaves it alone (written by k_queue_mesh)
     uint32_t* heavy_a;        // the early list: entries of queue_in (k_queue_mesh writes it, a mode-2 launch reads it as its `heavy`)
     uint32_t* hcount_a;
-    uint32_t bverdict_decay;  // the view differs from the one the verdicts were given under: a verdict that is used loses one of its frames
+    uint32_t bverdict_epoch;  // number of the VIEW (never 0; the host counts a new one whenever the frame's parameters change).  A verdict is the
+                              // number of the view it was given under and counts only under that very view, where it is exact (the same
+                              // bundle would give up again).  Verdicts of OTHER views were tried as guesses (eight frames each): a tile wrongly
+                              // sent one ray per wave costs 64 waves where a wrong "bundle" costs one budget-long wave — after a camera
+                              // move the home view ran at 10-11 ms for eight frames (profiles/r06_experiments_log.md 4): not used
     float single_look, single_band; // look-ahead / band of the one-ray-per-wave mode
 };
 
@@ -210,7 +214,6 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
 //, [3R+3] rays on the EARLY heavy list (bundle verdicts: RenderArgs::bverdict), [3R+4] its draw counter
 constexpr int kWfCounters = 3 * kMaxBundleRounds + 5;
-constexpr uint32_t kBundleVerdictFrames = 8u; // frames under a CHANGING view that a tile's "not a bundle" verdict holds before its rays are tried as a bundle again (a standing view keeps it)
 constexpr uint32_t kTileOvfEntries = 96u; // per-lane capacity of a window-overflow bag
 constexpr uint32_t kTileOvfSub = 32u;     // ... handed out this many entries at a time: a chunk of the pool = 32 entries x 64 lanes
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfSub * 64 * 16; // 32 KiB; a tile holds up to kTileOvfEntries / kTileOvfSub of them
@@ -373,6 +376,7 @@ struct grt_ctx {
     uint32_t bv_cap = 0;          // units d_bverdict holds
     uint64_t bv_sig[6] = {0, 0, 0, 0, 0, 0}; // launch geometry the verdicts belong to
     uint64_t bv_epoch = ~0ull;    // scene epoch they belong to
+    uint32_t bv_view = 1;         // number of the current view (RenderArgs::bverdict_epoch)
     grt_params bv_params;         // view of the last mesh frame that used or gave verdicts
     bool bv_params_valid = false;
     uint32_t* d_qcount = nullptr;                 // one chunk counter per stage (kMaxBundleRounds + 1)

@@ -300,12 +300,12 @@ __global__ __launch_bounds__(kBlock) void k_queue_mesh(const RenderArgs a)
     a.prec[i * 3 + 1] = make_float4(curO.z, curD.x, curD.y, curD.z);
     a.prec[i * 3 + 2] = make_float4(normal.x, normal.y, normal.z, 0.0f);
     // Bundle verdicts (first round only): a wave is one chunk = the bounced rays of one 8x8 tile.  A tile that gave up as a bundle in an
-    // earlier frame (RenderArgs::bverdict) has its rays put on the early list of the one-ray-per-wave kernel here, and its chunk is
+    // earlier frame OF THIS VIEW (RenderArgs::bverdict) has its rays put on the early list of the one-ray-per-wave kernel here, and its chunk is
     // marked for the bundle kernel to skip: the two kernels then run side by side, and the bundle that would be thrown away is not run.
     if (a.bverdict) {
         const uint32_t chunk = (uint32_t)(i >> 6);
         const uint32_t u = a.qunit[chunk];
-        const uint32_t v = a.bverdict[u];
+        const bool v = a.bverdict[u] == a.bverdict_epoch; // given under this very view: exact (verdicts of other views do not count)
         if (lane == 0) a.qskip[chunk] = v ? 1u : 0u;
         if (v) {
             const uint64_t vm = __ballot(have_ray);
@@ -313,7 +313,6 @@ __global__ __launch_bounds__(kBlock) void k_queue_mesh(const RenderArgs a)
             if (lane == 0) base = atomicAdd(a.hcount_a, (uint32_t)__popcll(vm));
             base = (uint32_t)__shfl((int)base, 0);
             if (have_ray) a.heavy_a[base + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = (uint32_t)i;
-            if (a.bverdict_decay && lane == 0) a.bverdict[u] = v - 1u; // under a changing view a verdict is used up; a standing one keeps it
         }
     }
     if (COUNT) {

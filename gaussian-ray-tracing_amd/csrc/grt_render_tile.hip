@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
         if (lane == 0) base = atomicAdd(a.hcount, (uint32_t)__popcll(vm));
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (in_frame) a.heavy[base + lanes_below(vm)] = (uint32_t)ent;
-        if (a.bverdict && lane == 0) a.bverdict[a.qunit[unit_s]] = kBundleVerdictFrames; // the tile is no bundle: remembered (RenderArgs::bverdict)
+        if (a.bverdict && lane == 0) a.bverdict[a.qunit[unit_s]] = a.bverdict_epoch; // the tile is no bundle under THIS view: remembered (RenderArgs::bverdict)
         gave_up = true;
         break;
     }

@@ -221,19 +221,20 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            none otherwise; 0: none; n (<= 8): n sweeps on any tree.  Levels and the reported height
                                            (grt_bvh_info) are re-derived behind every sweep.  Culling structure only: same pixels */,
        GRT_OPT_BUNDLE_PREDICT = 36      /* mesh frames on the tile kernel.  1 (default): an 8x8 tile whose bounced rays gave up as a bundle
-                                           (GRT_OPT_BUNDLE_BUDGET) is remembered; in the next frames its continuation rays go one per wave at
-                                           once, on a list that the one-ray-per-wave kernel works off BESIDE the bundle kernel (second
-                                           stream) instead of behind it, and the bundle that would be thrown away is not run.  A standing view
-                                           keeps its verdicts, a changing one uses each up in eight frames, a new scene / frame geometry starts
-                                           afresh.  0: every tile is tried as a bundle every frame (round 5).  Same rays through the same two
-                                           kernels: same pixels */,
+                                           (GRT_OPT_BUNDLE_BUDGET) is remembered FOR THE VIEW it happened under; while that view stands, its
+                                           continuation rays go one per wave at once, on a list that the one-ray-per-wave kernel works off
+                                           BESIDE the bundle kernel (second stream) instead of behind it, and the bundle that would be thrown
+                                           away is not run.  A frame with other parameters (a camera that moves), another scene, frame
+                                           geometry or budget uses no verdicts: every tile is tried as a bundle, as in round 5.  0: always
+                                           so.  Same rays through the same two kernels: same pixels */,
        GRT_OPT_MESH_PRIMARY_WAVE = 37   /* mesh frames, stage 1 (camera ray -> closest mesh hit -> closest-hit shading: traceMesh of
                                            shaders/tracer.cuh:266-287, shaders/tracer.cu:112-122,155-187).  0: every lane walks the mesh
                                            tree alone, in a kernel of its own in front of the Gaussian stage (rounds 1-5); 1: the 64 rays
                                            of an 8x8 tile walk it TOGETHER (nodes and triangles by scalar loads, a child is entered when
                                            any lane wants it, one stack per wave), still a kernel of its own; 2 (default): that walk runs
                                            at the head of the tile kernel's primary stage — no launch, no 48-B record per pixel (other
-                                           pipelines, and mesh trees too deep for the tile kernel's stack: as 1).  Every lane walks it alone (rounds 1-5).  The same hit records bit for bit */ };
+                                           pipelines, and mesh trees too deep for the tile kernel's stack: as 1).  The same hit records bit for
+                                           bit */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);

@@ -511,9 +511,9 @@ def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
               "deep": (4, 24, 16), "one round": (1, 64, 128)}
     segs = set()
     # (round 6: bundle verdicts, GRT_OPT_BUNDLE_PREDICT — a tile whose bounced rays gave up as a bundle sends them one per wave at
-    #  once in the following frames, beside the bundle kernel on a second stream.  Every route runs with verdicts off (one frame: round
-    #  5's pipeline) and on (three frames of a standing view: the first gives the verdicts, the next two use them), and under a view
-    #  that changes every frame — a verdict is then used up in eight frames and the tile is tried as a bundle again)
+    #  once in the following frames of the SAME view, beside the bundle kernel on a second stream.  Every route runs with verdicts off
+    #  (one frame: round 5's pipeline) and on (three frames of a standing view: the first gives the verdicts, the next two use them),
+    #  and under views that change — below)
     for name, (rounds, budget, lane_budget) in routes.items():
         for predict, n_frames in ((0, 1), (1, 3)):
             t.set_option(grt.OPT_BUNDLE_PREDICT, predict)
@@ -529,19 +529,21 @@ def test_bounce_pipeline_every_route_gives_the_same_frame(mesh_type, sh_degree):
                 segs.add((cnt["segments"], cnt["hit_evals"]))
     assert len(segs) == 1  # the same segments and the same composited events on every route
     if sh_degree == 0:
-        # a view that changes every frame (the eye wobbles, 12 frames: verdicts given, used, used up, given again): each frame equals
-        # the per-lane megakernel's frame of the same view
+        # views that change (the eye wobbles): a verdict counts only under the view it was given in, so a frame with other parameters
+        # uses none, the second frame of a view that stands uses the first one's, and coming back to a view seen before starts over —
+        # each frame equals the per-lane megakernel's frame of the same view
         t.set_option(grt.OPT_BUNDLE_ROUNDS, 2); t.set_option(grt.OPT_BUNDLE_BUDGET, 48); t.set_option(grt.OPT_LANE_BUDGET, 128)
         ref_t = grt.Tracer(0)
         ref_t.set_option(grt.OPT_KERNEL, 1)
         ref_t.upload(acts)
         ref_t.set_meshes(meshes)
-        for k in range(12):
+        for k, repeats in enumerate((1, 1, 3, 1, 2, 1, 1, 2)):
             q = grt.default_params(192, 160, center, mesh_type=mesh_type, max_bounces=8, sh_degree=sh_degree,
                                    eye=(0.02 * (k % 3), 0.01 * (k % 2), 3.0))
-            u8, f32 = t.render(q, want_f32=True)
             r8, rf = ref_t.render(q, want_f32=True)
-            assert bool((u8 == r8).all()) and bool((f32 == rf).all()), ("moving view", k)
+            for j in range(repeats):
+                u8, f32 = t.render(q, want_f32=True)
+                assert bool((u8 == r8).all()) and bool((f32 == rf).all()), ("changing views", k, j)
         t.check()
         ref_t.close()
     with pytest.raises(grt.GrtError):
