@@ -333,6 +333,16 @@ def test_isa_budget_of_the_render_kernels():
             assert k["lane_moves_in_loops"] <= 260 and k["spill_instructions_in_loops"] <= 60, (name, k)
         if mode == 2:
             assert k["lane_moves_in_loops"] <= 400 and k["spill_instructions_in_loops"] <= 24, (name, k)
+    # round 6: C4's critical path is the primary stage (with stage 1 — the tile's rays walking the mesh tree together — fused into its
+    # head) and then the one-ray-per-wave kernel; the bundle kernel runs in that kernel's shadow.  The fused instantiation spills more
+    # OUTSIDE its loops (85 VGPRs, 34 instructions) and must keep its loops clean; mode 2 stands at 372 lane moves in loops, mode 1 at
+    # 250 / 23 (VERDICT r05 asked for <= 250 / <= 8 there: not done — see profiles/r06_experiments_log.md 4)
+    c4 = b["grt::k_render_tile<false, false, true, 0, false>"]
+    assert c4["spill_instructions_in_loops"] == 0 and c4["lane_moves_in_loops"] <= 150 and c4["spill_instructions"] <= 40, c4
+    m1 = b["grt::k_render_tile<false, false, true, 1, false>"]
+    m2 = b["grt::k_render_tile<false, false, true, 2, false>"]
+    assert m1["instructions"] > 4000, m1  # (the budget reads a kernel to the END of its function: the bundle kernel has an early exit)
+    assert m1["spill_instructions_in_loops"] <= 30 and m2["lane_moves_in_loops"] <= 390 and m2["spill_instructions"] == 0, (m1, m2)
     c5 = b["grt::k_render_tile<false, false, false, 0, true>"]  # the same with pieces (needle / sheet scenes)
     assert c5["spill_instructions_in_loops"] <= 2 and c5["spill_instructions"] <= 16, c5  # (two in its piece-ownership block)
 
