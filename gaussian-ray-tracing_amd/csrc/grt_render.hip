@@ -614,6 +614,10 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             if (err) *err = "wavefront pipeline: continuation buffers missing";
             return GRT_ERR_INVALID;
         }
+        // (the kernels that walk only the MESH tree per lane — stage 1's per-lane form, k_queue_mesh — need LDS stacks as deep as THAT tree,
+        //  not as the Gaussian tree whose height `stack_depth` also covers (1 M Gaussians: 30 levels = 30 KB per workgroup, five workgroups
+        //  per CU; the 32 k-face sphere: 17): more of these latency-bound waves are resident)
+        const size_t lds_mesh = a.mstack_depth ? std::min(lds, (size_t)kBlock * sizeof(uint32_t) * a.mstack_depth) : lds;
         // counters of the pipeline: see kWfCounters (grt_internal.h)
         hipError_t e = hipMemsetAsync(a.qcount, 0, sizeof(uint32_t) * kWfCounters, stream);
         auto fp = count ? k_primary_mesh<true> : k_primary_mesh<false>;
@@ -632,7 +636,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             auto fw = count ? k_primary_mesh_wave<true> : k_primary_mesh_wave<false>;
             hipLaunchKernelGGL(fw, dim3(a.n_blocks), dim3(kBlock), sizeof(uint32_t) * 4u * a.mstack_depth, stream, a);
         } else {
-            hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds, stream, a);
+            hipLaunchKernelGGL(fp, dim3(a.n_blocks), dim3(kBlock), lds_mesh, stream, a);
         }
         int rc = tile_kernel ? launch_render_tile(a, count, true, 0, stream, err) : launch_render_stream(a, count, true, stream, aux, err);
         if (rc != GRT_OK) return rc;
@@ -657,7 +661,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
             const bool early = predict && r == 0; // bundle verdicts apply to the rays of the primary stage's tiles
             if (early) { b.bverdict = a.bverdict; b.qunit = a.qunit; b.qskip = a.qskip; b.heavy_a = a.heavy_a; b.hcount_a = a.qcount + 3 * kMaxBundleRounds + 3; }
-            hipLaunchKernelGGL(fq, dim3(qblocks), dim3(kBlock), lds, stream, b);
+            hipLaunchKernelGGL(fq, dim3(qblocks), dim3(kBlock), lds_mesh, stream, b);
             if (early) {
                 // the tiles known not to be bundles go one ray per wave BESIDE the bundle kernel: the bundles first (short waves, they take
                 // the machine and leave it within ~0.1 ms), the resident one-ray-per-wave grid on the second stream fills in behind them
