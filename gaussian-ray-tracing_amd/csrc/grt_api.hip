@@ -1519,7 +1519,7 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
         a.queue_alt = c->d_queue + c->wf_cap * 4;
         a.heavy = c->d_heavy; a.fqueue = c->d_fqueue;
     }
-    a.bverdict = nullptr; a.qunit = nullptr; a.qskip = nullptr; a.heavy_a = nullptr; a.hcount_a = nullptr; a.bverdict_epoch = 0;
+    a.bverdict = nullptr; a.qunit = nullptr; a.qunit_out = nullptr; a.qunit_cap = 0; a.qskip = nullptr; a.heavy_a = nullptr; a.hcount_a = nullptr; a.bverdict_epoch = 0;
     const bool tile_kernel = uses_tile_kernel(c->opt_kernel, a.mode, depth, sc->built_leaf_max, sc->gbvh.n_prims);
     if (sc->n_faces && a.mode != 2 && tile_kernel && c->opt_bundle_predict && c->opt_bundle_rounds > 0 && c->wf_cap) {
         // bundle verdicts (RenderArgs::bverdict): one word per 8x8 tile of the launch; they belong to a launch geometry and a scene —
@@ -1534,20 +1534,20 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
             (void)hipFree(c->d_bverdict); (void)hipFree(c->d_qunit); (void)hipFree(c->d_qskip); (void)hipFree(c->d_heavy_a);
             c->d_bverdict = c->d_qunit = c->d_qskip = c->d_heavy_a = nullptr;
             c->bv_cap = 0;
-            CHK(c, hipMalloc(&c->d_bverdict, sizeof(uint32_t) * nu));
-            CHK(c, hipMalloc(&c->d_qunit, sizeof(uint32_t) * chunks));
+            CHK(c, hipMalloc(&c->d_bverdict, sizeof(uint32_t) * (size_t)nu * kMaxBundleRounds)); // (a set of verdicts per bundle round)
+            CHK(c, hipMalloc(&c->d_qunit, sizeof(uint32_t) * 2 * chunks));                       // (tile numbers of the chunks of either queue)
             CHK(c, hipMalloc(&c->d_qskip, sizeof(uint32_t) * chunks));
             CHK(c, hipMalloc(&c->d_heavy_a, sizeof(uint32_t) * c->wf_cap));
             c->bv_cap = nu;
             fresh = true;
         }
         if (fresh || memcmp(sig, c->bv_sig, sizeof(sig)) != 0 || c->bv_epoch != sc->scene_epoch) {
-            CHK(c, hipMemsetAsync(c->d_bverdict, 0, sizeof(uint32_t) * nu, s)); // (on the frame's stream: ordered against its kernels)
+            CHK(c, hipMemsetAsync(c->d_bverdict, 0, sizeof(uint32_t) * (size_t)nu * kMaxBundleRounds, s)); // (on the frame's stream: ordered against its kernels)
             memcpy(c->bv_sig, sig, sizeof(sig));
             c->bv_epoch = sc->scene_epoch;
             c->bv_params_valid = false;
         }
-        a.bverdict = c->d_bverdict; a.qunit = c->d_qunit; a.qskip = c->d_qskip; a.heavy_a = c->d_heavy_a;
+        a.bverdict = c->d_bverdict; a.qunit = c->d_qunit; a.qunit_cap = (uint32_t)chunks; a.qskip = c->d_qskip; a.heavy_a = c->d_heavy_a;
         if (!(c->bv_params_valid && memcmp(&c->bv_params, &a.p, sizeof(grt_params)) == 0)) c->bv_view = (c->bv_view + 1u) ? c->bv_view + 1u : 1u; // another view (never 0: a cleared word is no verdict)
         a.bverdict_epoch = c->bv_view;
         c->bv_params = a.p;
@@ -1669,7 +1669,8 @@ static int do_launch(grt_ctx* c, RenderArgs& a, void* stream)
             for (int k = 0; k <= kMaxBundleRounds; k++) t += " " + std::to_string(q[k]);
             t += " | heavy rays per round:";
             for (int k = 0; k < kMaxBundleRounds; k++) t += " " + std::to_string(q[kMaxBundleRounds + 1 + k]);
-            t += " | retry queue: " + std::to_string(q[2 * kMaxBundleRounds + 1]) + " | early list (tiles known not to be bundles): " + std::to_string(q[3 * kMaxBundleRounds + 3]) + " rays";
+            t += " | retry queue: " + std::to_string(q[2 * kMaxBundleRounds + 1]) + " | early lists per round (tiles known not to be bundles):";
+            for (int k = 0; k < kMaxBundleRounds; k++) t += " " + std::to_string(q[3 * kMaxBundleRounds + 3 + 2 * k]);
             fprintf(stderr, "%s\n", t.c_str());
         }
     }

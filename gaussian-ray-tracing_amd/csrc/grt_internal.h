@@ -151,8 +151,11 @@ struct RenderArgs {
     // a bundle is remembered, and the next frames send its continuation rays one per wave AT ONCE — on a list of their own that the
     // one-ray-per-wave kernel works off BESIDE the bundle kernel (second stream) instead of behind it, and without the budget-long bundle
     // that is thrown away.  Same rays through the same two kernels as before, so the same pixels.
-    uint32_t* bverdict;       // [n_units] frames the verdict still holds; 0 = the tile's continuation rays are traced as a bundle
-    uint32_t* qunit;          // [chunks of the first queue] the unit (8x8 tile) whose primary-stage wave wrote the chunk
+    uint32_t* bverdict;       // [bundle round][n_units] the number of the view under which the tile's rays of that round gave up as a bundle (0 = never)
+    uint32_t* qunit;          // [chunks] the unit (8x8 tile) a chunk's rays belong to — of the queue the primary stage WRITES, of the queue a
+                              // bundle round READS; `qunit_out`: of the queue a bundle round writes (the tile's number travels with its rays)
+    uint32_t* qunit_out;
+    uint32_t qunit_cap;       // chunks one queue's array of tile numbers holds (the second queue's array follows the first's)
     uint32_t* qskip;          // [chunks] 1 = the chunk's rays are on the early list: the bundle kernel leaves it alone (written by k_queue_mesh)
     uint32_t* heavy_a;        // the early list: entries of queue_in (k_queue_mesh writes it, a mode-2 launch reads it as its `heavy`)
     uint32_t* hcount_a;
@@ -212,8 +215,8 @@ constexpr int kMaxBundleRounds = 4; // GRT_OPT_BUNDLE_ROUNDS <= this
 // counters of the wavefront pipeline (one uint32 each, zeroed per frame): [0 .. R] chunks written by stage 2 and by bundle
 // round r, [R+1 .. 2R] rays on the heavy list of round r, [2R+1] entries of the retry queue, [2R+2 .. 3R+1] the draw
 // counter of round r's one-ray-per-wave launch, [3R+2] the draw counter of the last one
-//, [3R+3] rays on the EARLY heavy list (bundle verdicts: RenderArgs::bverdict), [3R+4] its draw counter
-constexpr int kWfCounters = 3 * kMaxBundleRounds + 5;
+//, [3R+3+2r] rays on round r's EARLY heavy list (bundle verdicts: RenderArgs::bverdict), [3R+4+2r] its draw counter
+constexpr int kWfCounters = 5 * kMaxBundleRounds + 3;
 constexpr uint32_t kTileOvfEntries = 96u; // per-lane capacity of a window-overflow bag
 constexpr uint32_t kTileOvfSub = 32u;     // ... handed out this many entries at a time: a chunk of the pool = 32 entries x 64 lanes
 constexpr size_t kTileOvfChunkBytes = (size_t)kTileOvfSub * 64 * 16; // 32 KiB; a tile holds up to kTileOvfEntries / kTileOvfSub of them

@@ -653,16 +653,20 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
         const uint32_t rounds = tile_kernel ? std::min<uint32_t>(a.bundle_rounds, (uint32_t)kMaxBundleRounds) : 0u;
         b.fcount = a.qcount + 2 * kMaxBundleRounds + 1;
         const bool predict = tile_kernel && a.bverdict && a.qunit && a.qskip && a.heavy_a && aux && aux->aux && aux->fork && aux->join;
-        b.bverdict = nullptr; b.qunit = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
+        uint32_t* const qun[2] = {a.qunit, a.qunit ? a.qunit + a.qunit_cap : nullptr}; // the tile numbers of the chunks of q[0] / q[1]
+        b.bverdict = nullptr; b.qunit = nullptr; b.qunit_out = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
         for (uint32_t r = 0; r < rounds; r++) {
             b.queue_in = q[in]; b.qcount_in = a.qcount + stage;
             b.queue = q[in ^ 1u]; b.qcount = a.qcount + stage + 1u;
             b.hcount = a.qcount + kMaxBundleRounds + 1 + r;
             b.hnext = a.qcount + 2 * kMaxBundleRounds + 2 + r;
-            const bool early = predict && r == 0; // bundle verdicts apply to the rays of the primary stage's tiles
-            if (early) { b.bverdict = a.bverdict; b.qunit = a.qunit; b.qskip = a.qskip; b.heavy_a = a.heavy_a; b.hcount_a = a.qcount + 3 * kMaxBundleRounds + 3; }
+            // bundle verdicts, per round: the tiles whose rays of THIS round gave up as a bundle under this view
+            if (predict) {
+                b.bverdict = a.bverdict + (size_t)r * a.n_blocks * 4u; b.qunit = qun[in]; b.qunit_out = qun[in ^ 1u]; b.qskip = a.qskip; b.heavy_a = a.heavy_a;
+                b.hcount_a = a.qcount + 3 * kMaxBundleRounds + 3 + 2 * r;
+            }
             hipLaunchKernelGGL(fq, dim3(qblocks), dim3(kBlock), lds_mesh, stream, b);
-            if (early) {
+            if (predict) {
                 // the tiles known not to be bundles go one ray per wave BESIDE the bundle kernel: the bundles first (short waves, they take
                 // the machine and leave it within ~0.1 ms), the resident one-ray-per-wave grid on the second stream fills in behind them
                 if ((e = hipEventRecord(aux->fork, stream)) != hipSuccess || (e = hipStreamWaitEvent(aux->aux, aux->fork, 0)) != hipSuccess) {
@@ -671,9 +675,9 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
                 }
             }
             rc = launch_render_tile(b, count, true, 1, stream, err);          // bundles; chunks over budget -> heavy list
-            if (rc == GRT_OK && early) {
+            if (rc == GRT_OK && predict) {
                 RenderArgs s1 = b;
-                s1.heavy = a.heavy_a; s1.hcount = b.hcount_a; s1.hnext = a.qcount + 3 * kMaxBundleRounds + 4;
+                s1.heavy = a.heavy_a; s1.hcount = b.hcount_a; s1.hnext = a.qcount + 3 * kMaxBundleRounds + 4 + 2 * r;
                 rc = launch_render_tile(s1, count, true, 2, aux->aux, err);   // the early list: one ray per wave, to their end
                 if (rc == GRT_OK && ((e = hipEventRecord(aux->join, aux->aux)) != hipSuccess || (e = hipStreamWaitEvent(stream, aux->join, 0)) != hipSuccess)) {
                     if (err) *err = std::string("wavefront pipeline: join of the second stream: ") + hipGetErrorString(e);
@@ -682,7 +686,7 @@ int launch_render(const RenderArgs& a, bool count, int kernel_variant, uint32_t 
             }
             if (rc == GRT_OK) rc = launch_render_tile(b, count, true, 2, stream, err); // the rays of the chunks that gave up now: one per wave, to their end
             if (rc != GRT_OK) return rc;
-            b.bverdict = nullptr; b.qunit = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
+            b.bverdict = nullptr; b.qunit = nullptr; b.qunit_out = nullptr; b.qskip = nullptr; b.heavy_a = nullptr; b.hcount_a = nullptr;
             in ^= 1u;
             stage++;
         }

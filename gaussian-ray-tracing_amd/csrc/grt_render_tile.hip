@@ -1540,7 +1540,9 @@ __global__ __launch_bounds__(kWG, MODE == 2 ? GRT_TILE_WAVES2 : (MODE == 3 ? kWa
             if (lane == 0) base = atomicAdd(a.qcount, 1u);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             float4* q = a.queue + ((size_t)base * 64u + lane) * 4;
-            if (MODE == 0 && a.qunit && lane == 0) a.qunit[base] = ue & kOrderUnitMask; // whose chunk it is (bundle verdicts)
+            // whose chunk it is (bundle verdicts): the tile's number, and it travels with the tile's rays from round to round
+            if (MODE == 0 && a.qunit && lane == 0) a.qunit[base] = ue & kOrderUnitMask;
+            if (MODE == 1 && a.qunit_out && lane == 0) a.qunit_out[base] = a.qunit[unit_s];
             if (cont) {
                 q[0] = make_float4(nextO.x, nextO.y, nextO.z, nextD.x);
                 q[1] = make_float4(nextD.y, nextD.z, accumColor.x, accumColor.y);
