@@ -639,7 +639,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_BVH_ROTATIONS) { NOT_A_VIEW(c, "GRT_OPT_BVH_ROTATIONS"); c->opt_bvh_rotations = value < 0 ? -1 : (value > 8 ? 8 : value); }
-    else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = std::min(1024, std::max(0, value)); }
+    else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = value < 0 ? -1 : std::min(1024, value); }
     else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
     else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; c->ovf_sized = false; }
     else if (option == GRT_OPT_OVF_ENTRIES) {
@@ -747,7 +747,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         hipLaunchKernelGGL(k_proxy_boxes, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat,
                            d_s, n, d_lo, d_hi);
     }
-    if (rc == GRT_OK && c->opt_split > 0 && n > 1) {
+    if (rc == GRT_OK && c->opt_split != 0 && n > 1) {
         // ---- spatial splits (see k_piece_boxes): piece length = opt_split/4 x the geometric-mean proxy diagonal ----
         float* d_part = nullptr;
         uint32_t* d_pcnt = nullptr;
@@ -769,30 +769,46 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         if (rc == GRT_OK) {
             double sum = 0.0; uint64_t cnt = 0;
             for (int b = 0; b < grid; b++) { sum += h_part[b]; cnt += h_pcnt[b]; }
-            if (cnt) { c->gm_diag = (float)std::exp(sum / (double)cnt); tau = 0.25f * (float)c->opt_split * c->gm_diag; }
+            if (cnt) { c->gm_diag = (float)std::exp(sum / (double)cnt); tau = 0.25f * (float)(c->opt_split < 0 ? 8 : c->opt_split) * c->gm_diag; }
         }
+        // pieces at a given piece length: per-proxy counts (d_cnt), their exclusive scan (d_offs) and the total, summed in 64 bits (the scan runs in
+        // 32 bits: 512 pieces per particle times 2^26 particles could wrap it; a scene whose pieces would not fit the leaf index keeps whole proxies)
+        auto count_pieces = [&](float tau_, uint64_t& total_) -> int {
+            hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau_, d_cnt);
+            if (device_exclusive_scan_u32(d_cnt, d_offs, n, c->stream, &c->err) != GRT_OK) return GRT_ERR_HIP;
+            unsigned long long* d_tot = nullptr;
+            unsigned long long h_tot = 0;
+            hipError_t e_ = hipMalloc(&d_tot, sizeof(*d_tot));
+            if (e_ == hipSuccess) e_ = hipMemsetAsync(d_tot, 0, sizeof(*d_tot), c->stream);
+            if (e_ == hipSuccess) {
+                hipLaunchKernelGGL(k_sum_u32, dim3(std::min<uint32_t>((uint32_t)((n + 255) / 256), 1024u)), dim3(256), 0, c->stream, d_cnt, n, d_tot);
+                if ((e_ = hipMemcpyAsync(&h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, c->stream)) == hipSuccess) e_ = hipStreamSynchronize(c->stream);
+            }
+            (void)hipFree(d_tot);
+            if (e_ != hipSuccess) { c->err = std::string("grt_build_bvh: piece total: ") + hipGetErrorString(e_); return GRT_ERR_HIP; }
+            total_ = h_tot;
+            return GRT_OK;
+        };
         if (rc == GRT_OK && tau > 0.0f) {
-            hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau, d_cnt);
-            if (device_exclusive_scan_u32(d_cnt, d_offs, n, c->stream, &c->err) != GRT_OK) rc = GRT_ERR_HIP;
-            e = hipSuccess;
-            uint32_t last_off = 0, last_cnt = 0;
-            if (e == hipSuccess) e = hipMemcpyAsync(&last_off, d_offs + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(&last_cnt, d_cnt + (n - 1), 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { c->err = std::string("grt_build_bvh: split scan: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
-            uint64_t total = (uint64_t)last_off + last_cnt;
-            // (the scan runs in 32 bits: 512 pieces per particle times 2^26 particles could wrap it — the true total is summed in
-            //  64 bits beside it, and a scene whose pieces would not fit the leaf index keeps whole proxies)
-            if (rc == GRT_OK) {
-                unsigned long long* d_tot = nullptr;
-                unsigned long long h_tot = 0;
-                if ((e = hipMalloc(&d_tot, sizeof(*d_tot))) == hipSuccess && (e = hipMemsetAsync(d_tot, 0, sizeof(*d_tot), c->stream)) == hipSuccess) {
-                    hipLaunchKernelGGL(k_sum_u32, dim3(std::min<uint32_t>((uint32_t)((n + 255) / 256), 1024u)), dim3(256), 0, c->stream, d_cnt, n, d_tot);
-                    if ((e = hipMemcpyAsync(&h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, c->stream)) == hipSuccess) e = hipStreamSynchronize(c->stream);
+            uint64_t total = 0;
+            rc = count_pieces(tau, total);
+            // GRT_OPT_SPLIT < 0 (default): the piece length follows the scene.  Measured on the 1 M scene with per-axis log-scale noise sigma
+            // (profiles/r06_experiments_log.md 9; kernel ms at piece lengths 3 / 4 / 5 / 6 / 8 quarters of the typical diagonal): sigma 0.7: 2.61 /
+            // 2.62 / 2.66 / 2.71 / 3.81 (at 8 nothing is split); 0.85: 3.11 / 3.12 / 3.21 / 3.27 / 3.46; 1.0: 3.90 / 3.84 / 3.85 / 3.93 / 4.31; 1.2:
+            // 6.92 / 6.27 / 6.20 / 6.16 / 6.40; 1.4: 13.8 / 12.2 / 11.6 / 11.2 / 11.6; 1.6: 22.5 (4) / 14.5 (6) / 13.8 (8).  The mildly anisotropic
+            // scene wants SHORT pieces (its proxies are a few times longer than thick: cut at 8 quarters nearly none qualifies), the scene of
+            // scene-sized needles long ones (every piece re-tests its particle).  The share of primitives that splitting at 8 adds tells them
+            // apart: below 15 % -> 4, below 50 % -> 6, else 8.
+            if (rc == GRT_OK && c->opt_split < 0) {
+                const double r8 = (double)total / (double)n;
+                const int q = r8 < 1.15 ? 4 : (r8 < 1.5 ? 6 : 8);
+                if (q != 8) {
+                    tau = 0.25f * (float)q * c->gm_diag;
+                    rc = count_pieces(tau, total);
                 }
-                (void)hipFree(d_tot);
-                if (e != hipSuccess) { c->err = std::string("grt_build_bvh: piece total: ") + hipGetErrorString(e); rc = GRT_ERR_HIP; }
-                else total = h_tot;
+                c->split_used = q;
+            } else {
+                c->split_used = c->opt_split;
             }
             // (a scene where splitting adds less than 2 % of primitives has no population of needles and sheets to speak of:
             //  it keeps whole proxies — size classes deal with the odd large one — and the kernels without the piece logic)

@@ -172,8 +172,11 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_SINGLE_BAND = 19       /* one-ray-per-wave mode: as GRT_OPT_TILE_BAND (default 256 = 25 %) */,
        GRT_OPT_SPLIT = 24             /* spatial splits: a proxy much longer than the typical one whose world box is mostly empty (a needle or
                                          sheet that is not axis-aligned) enters the LBVH as up to 512 pieces, each with the box of its cell;
-                                         value = piece length in quarters of the geometric-mean proxy diagonal (default 8 = 2 x; 0 = off).
-                                         Pure acceleration structure: same hits, same pixels.  Per context; next build */,
+                                         value = piece length in quarters of the geometric-mean proxy diagonal (8 = 2 x; 0 = off).  Default -1:
+                                         the length follows the scene — 4 when cutting at 8 would add under 15 % of primitives (mildly
+                                         anisotropic proxies, a few times longer than thick: a trained scene), 6 under 50 %, else 8 (scene-sized
+                                         needles and sheets, where every piece re-tests its particle).  Pure acceleration structure: same hits,
+                                         same pixels.  Per context; next build */,
        GRT_OPT_TILE_BAND_ABS = 25     /* trees with pieces: absolute floor of the tile kernel's leaf band and node look-ahead, in 1/64 of the
                                          geometric-mean proxy diagonal (default 512 = 8 x; 0 = relative bands only).  Scheduling only */,
        /* testing knobs (frames never change; speed and the failure signal do) */

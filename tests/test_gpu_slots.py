@@ -309,7 +309,7 @@ def test_spatial_splits_are_pure_acceleration_structure(fisheye):
     center = grt.gaussian_center(acts["pos"])
     p = grt.default_params(W, H, center, fisheye=fisheye)
     frames, cnts, infos = {}, {}, {}
-    for split, kernel in ((0, 0), (8, 0), (3, 0), (8, 3), (8, 1), (8, 2), (64, 0)):
+    for split, kernel in ((0, 0), (8, 0), (3, 0), (8, 3), (8, 1), (8, 2), (64, 0), (-1, 0), (-1, 3)):  # (-1: the piece length follows the scene, the default)
         t = grt.Tracer(0)
         t.set_option(grt.OPT_SPLIT, split)
         t.set_option(grt.OPT_KERNEL, kernel)
@@ -326,6 +326,7 @@ def test_spatial_splits_are_pure_acceleration_structure(fisheye):
         assert bool((fr[0] == u8).all()) and bool((fr[1] == f32).all()), k
         assert cnts[k]["hit_evals"] == cnts[(0, 0)]["hit_evals"] and cnts[k]["stall_exits"] == 0, k
     i0, i1, i2 = infos[(0, 0)], infos[(8, 0)], infos[(3, 0)]
+    assert infos[(-1, 0)]["n_primitives"] > 1.2 * i0["n_proxies"]  # the default splits this scene too (sigma 1.6: at length 8)
     assert i0["n_primitives"] == i0["n_proxies"] == i1["n_proxies"]
     assert i2["n_primitives"] > i1["n_primitives"] > 1.2 * i1["n_proxies"]  # the needles and sheets did become pieces
     # ... and the tiles meet fewer empty boxes (on the 1 M needle scene C3a: 608 -> 70 boxes and 774 -> 390 exact tests per ray)
@@ -389,3 +390,43 @@ def test_tree_rotations_rederive_levels_and_height_and_keep_the_frame():
     compare(base[1], ref_f32, base[0], ref_u8)
     assert rc["hit_evals"] == base[2]
     sc.close()
+
+
+def test_piece_length_follows_the_scene():
+    """GRT_OPT_SPLIT = -1 (default): mildly anisotropic proxies (per-axis log-scale noise 0.8: a few times longer than thick — cut at 8
+    quarters of the typical diagonal nearly none of them qualifies) get SHORT pieces, scene-sized needles and sheets (noise 1.6) long
+    ones, an isotropic scene none.  Same bytes as without splits on every kernel, the oracle's frame, fewer boxes and tests per ray."""
+    W, H = 192, 128
+    for sigma, expect in ((0.0, "none"), (0.8, "short"), (1.6, "long")):
+        raw = grt.synth_scene(85, 30000)
+        if sigma:
+            raw["scale"] = (raw["scale"] + np.random.default_rng(5).normal(0.0, sigma, size=raw["scale"].shape)).astype(np.float32)
+        acts = grt.activate(raw)
+        p = grt.default_params(W, H, grt.gaussian_center(acts["pos"]))
+        res = {}
+        for split, kernel in ((0, 0), (-1, 0), (-1, 1), (-1, 3), (8, 0), (4, 0)):
+            t = grt.Tracer(0)
+            t.set_option(grt.OPT_SPLIT, split)
+            t.set_option(grt.OPT_KERNEL, kernel)
+            t.upload(acts)
+            t.set_option(grt.OPT_COUNTERS, 1)
+            u8, f32 = t.render(p, want_f32=True)
+            res[(split, kernel)] = (u8.clone(), f32.clone(), t.counters(), t.bvh_info())
+            t.check()
+            t.close()
+        u8, f32, c0, i0 = res[(0, 0)]
+        for k, (a8, af, c, i) in res.items():
+            assert bool((a8 == u8).all()) and bool((af == f32).all()) and c["hit_evals"] == c0["hit_evals"] and c["stall_exits"] == 0, (sigma, k)
+        n_auto, n8, n4 = (res[k][3]["n_primitives"] for k in ((-1, 0), (8, 0), (4, 0)))
+        if expect == "none":
+            assert n_auto == i0["n_proxies"] == n8
+        elif expect == "short":
+            assert n_auto == n4 > n8 >= i0["n_proxies"]  # the scene's pieces are the short ones
+            ca = res[(-1, 0)][2]
+            assert ca["node_visits"] + ca["proxy_tests"] < c0["node_visits"] + c0["proxy_tests"]
+        else:
+            assert n_auto == n8 > 1.2 * i0["n_proxies"] and n4 > n8
+        sc = O.Scene(acts_to_particles(acts))
+        ref_u8, ref_f32, rc = sc.render(to_oracle_params(p), threads=8)
+        compare(f32, ref_f32, u8, ref_u8)
+        sc.close()
