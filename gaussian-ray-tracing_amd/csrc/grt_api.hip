@@ -120,7 +120,7 @@ struct PieceGrid { uint32_t p[3]; };
 
 // how particle i is cut: pieces per principal axis (1,1,1 = not split).  tau = the piece length aimed at.
 __device__ __forceinline__ PieceGrid piece_grid(const float* __restrict__ scale, const float* __restrict__ quat, float s, uint32_t i,
-                                                float tau, float4 lo, float4 hi)
+                                                float tau, float4 lo, float4 hi, float volf)
 {
     PieceGrid g{{1u, 1u, 1u}};
     if (!(s > 0.0f) || !(tau > 0.0f)) return g;
@@ -145,7 +145,7 @@ __device__ __forceinline__ PieceGrid piece_grid(const float* __restrict__ scale,
         v1 *= fminf(2.0f * h, (k == 0) ? hi.x - lo.x : (k == 1) ? hi.y - lo.y : hi.z - lo.z);
     }
     const float v0 = (hi.x - lo.x) * (hi.y - lo.y) * (hi.z - lo.z);
-    if (!(v1 < 0.5f * v0)) return g;
+    if (!(v1 < volf * v0)) return g;
     g.p[0] = p[0]; g.p[1] = p[1]; g.p[2] = p[2];
     return g;
 }
@@ -160,19 +160,19 @@ __global__ void k_sum_u32(const uint32_t* __restrict__ v, uint64_t n, unsigned l
 }
 
 __global__ void k_piece_counts(const float* __restrict__ scale, const float* __restrict__ quat, const float* __restrict__ s_arr,
-                               const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, float tau,
+                               const float4* __restrict__ lo, const float4* __restrict__ hi, uint32_t n, float tau, float volf,
                                uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, lo[i], hi[i]);
+    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, lo[i], hi[i], volf);
     counts[i] = g.p[0] * g.p[1] * g.p[2];
 }
 
 // one thread per piece: its owner by binary search in the offsets, its cell, its box
 __global__ void k_piece_boxes(const float* __restrict__ pos, const float* __restrict__ scale, const float* __restrict__ quat,
                               const float* __restrict__ s_arr, const float4* __restrict__ lo, const float4* __restrict__ hi,
-                              const uint32_t* __restrict__ offs, uint32_t n, uint32_t n_pieces, float tau,
+                              const uint32_t* __restrict__ offs, uint32_t n, uint32_t n_pieces, float tau, float volf,
                               float4* __restrict__ plo, float4* __restrict__ phi, uint32_t* __restrict__ owner,
                               uint32_t* __restrict__ desc)
 {
@@ -187,7 +187,7 @@ __global__ void k_piece_boxes(const float* __restrict__ pos, const float* __rest
     const uint32_t i = a;
     owner[j] = i;
     const float4 l = lo[i], h = hi[i];
-    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, l, h);
+    const PieceGrid g = piece_grid(scale, quat, s_arr[i], i, tau, l, h, volf);
     if (g.p[0] * g.p[1] * g.p[2] <= 1u) { plo[j] = l; phi[j] = h; return; }
     uint32_t q = j - offs[i];
     const uint32_t k0 = q % g.p[0]; q /= g.p[0];
@@ -639,6 +639,7 @@ int grt_set_option(grt_ctx* c, int option, int value)
     else if (option == GRT_OPT_SINGLE_BAND) { c->opt_single_band = std::max(0, value); }
     else if (option == GRT_OPT_SIZE_CLASSES) { NOT_A_VIEW(c, "GRT_OPT_SIZE_CLASSES"); c->opt_size_classes = value ? 1 : 0; }
     else if (option == GRT_OPT_BVH_ROTATIONS) { NOT_A_VIEW(c, "GRT_OPT_BVH_ROTATIONS"); c->opt_bvh_rotations = value < 0 ? -1 : (value > 8 ? 8 : value); }
+    else if (option == GRT_OPT_SPLIT_VOL_PCT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT_VOL_PCT"); c->opt_split_vol_pct = std::max(1, value); }
     else if (option == GRT_OPT_SPLIT) { NOT_A_VIEW(c, "GRT_OPT_SPLIT"); c->opt_split = value < 0 ? -1 : std::min(1024, value); }
     else if (option == GRT_OPT_TILE_BAND_ABS) { c->opt_band_abs = std::max(0, value); }
     else if (option == GRT_OPT_OVF_CHUNKS) { c->opt_ovf_chunks = value; c->ovf_demand = 0; c->ovf_hist_n = 0; c->ovf_short = false; c->ovf_sized = false; }
@@ -773,8 +774,9 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         }
         // pieces at a given piece length: per-proxy counts (d_cnt), their exclusive scan (d_offs) and the total, summed in 64 bits (the scan runs in
         // 32 bits: 512 pieces per particle times 2^26 particles could wrap it; a scene whose pieces would not fit the leaf index keeps whole proxies)
+        const float volf = 0.01f * (float)c->opt_split_vol_pct;
         auto count_pieces = [&](float tau_, uint64_t& total_) -> int {
-            hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau_, d_cnt);
+            hipLaunchKernelGGL(k_piece_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_scale, c->d_quat, d_s, d_lo, d_hi, n, tau_, volf, d_cnt);
             if (device_exclusive_scan_u32(d_cnt, d_offs, n, c->stream, &c->err) != GRT_OK) return GRT_ERR_HIP;
             unsigned long long* d_tot = nullptr;
             unsigned long long h_tot = 0;
@@ -792,16 +794,18 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
         if (rc == GRT_OK && tau > 0.0f) {
             uint64_t total = 0;
             rc = count_pieces(tau, total);
-            // GRT_OPT_SPLIT < 0 (default): the piece length follows the scene.  Measured on the 1 M scene with per-axis log-scale noise sigma
-            // (profiles/r06_experiments_log.md 9; kernel ms at piece lengths 3 / 4 / 5 / 6 / 8 quarters of the typical diagonal): sigma 0.7: 2.61 /
-            // 2.62 / 2.66 / 2.71 / 3.81 (at 8 nothing is split); 0.85: 3.11 / 3.12 / 3.21 / 3.27 / 3.46; 1.0: 3.90 / 3.84 / 3.85 / 3.93 / 4.31; 1.2:
-            // 6.92 / 6.27 / 6.20 / 6.16 / 6.40; 1.4: 13.8 / 12.2 / 11.6 / 11.2 / 11.6; 1.6: 22.5 (4) / 14.5 (6) / 13.8 (8).  The mildly anisotropic
-            // scene wants SHORT pieces (its proxies are a few times longer than thick: cut at 8 quarters nearly none qualifies), the scene of
-            // scene-sized needles long ones (every piece re-tests its particle).  The share of primitives that splitting at 8 adds tells them
-            // apart: below 15 % -> 4, below 50 % -> 6, else 8.
+            // GRT_OPT_SPLIT < 0 (default): the piece length follows the scene.  Measured on the 1 M scene with per-axis log-scale noise sigma,
+            // every proxy longer than the piece length cut (GRT_OPT_SPLIT_VOL_PCT = 400), kernel ms by length in quarters of the typical
+            // diagonal (profiles/r06_experiments_log.md 9): sigma 0.7: 2.29 (6) 2.28 (8) 2.57 (12); 0.85: 2.46 (6) 2.50 (8) 2.63 (10); 1.0: 2.97 (6)
+            // 3.00 (8) 3.45 (12); 1.2: 4.28 (6) 4.20 (8) 4.42 (10); 1.4: 8.31 (6) 7.67 (8) 7.60 (10) 8.07 (12); 1.6: 9.12 (8) 8.75 (10) 8.62 (12) 9.06
+            // (16); 2.0: 70 (8) 59 (12) 53 (16).  Mildly anisotropic proxies want SHORT pieces, scene-sized needles long ones (every piece
+            // re-tests its particle).  The primitives per proxy that cutting at 8 gives tell the scenes apart (1.10 / 1.16 / 1.23 / 1.37 /
+            // 1.56 / 1.82 / 2.62 for the sigmas above): under 1.25 -> 6, under 1.5 -> 8, under 1.7 -> 10, under 2.2 -> 12, else 16; and a scene
+            // that would gain under 2 % of primitives keeps whole proxies and the kernels without the piece logic (the benchmark scenes
+            // C1-C5: cut finer they only lose, 1.78 -> 1.86 ms at 3 % of pieces).
             if (rc == GRT_OK && c->opt_split < 0) {
                 const double r8 = (double)total / (double)n;
-                const int q = r8 < 1.15 ? 4 : (r8 < 1.5 ? 6 : 8);
+                const int q = r8 < 1.02 ? 8 : (r8 < 1.25 ? 6 : (r8 < 1.5 ? 8 : (r8 < 1.7 ? 10 : (r8 < 2.2 ? 12 : 16))));
                 if (q != 8) {
                     tau = 0.25f * (float)q * c->gm_diag;
                     rc = count_pieces(tau, total);
@@ -821,7 +825,7 @@ int grt_build_bvh(grt_ctx* c, float alpha_min)
                     rc = GRT_ERR_HIP;
                 } else {
                     hipLaunchKernelGGL(k_piece_boxes, dim3((n_pieces + 255) / 256), dim3(256), 0, c->stream, c->d_pos, c->d_scale, c->d_quat, d_s,
-                                       d_lo, d_hi, d_offs, n, n_pieces, tau, d_plo, d_phi, d_owner, d_desc);
+                                       d_lo, d_hi, d_offs, n, n_pieces, tau, volf, d_plo, d_phi, d_owner, d_desc);
                 }
             }
         }

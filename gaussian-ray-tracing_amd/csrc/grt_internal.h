@@ -282,8 +282,10 @@ struct grt_ctx {
     int opt_bvh_rotations = -1; // GRT_OPT_BVH_ROTATIONS
     int opt_band_abs = 512;       // GRT_OPT_TILE_BAND_ABS: that floor in 1/64 of the geometric-mean proxy diagonal
     float gm_diag = 0.f;          // geometric mean of the proxies' box diagonals (grt_build_bvh)
-    int opt_split = -1;           // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off; < 0 = by the scene: 4 / 6 / 8)
+    int opt_split = -1;           // GRT_OPT_SPLIT: piece length of the spatial splits in quarters of the typical proxy diagonal (0 = off; < 0 = by the scene: 6 .. 16)
     int split_used = 0;           // ... the length the last build used
+    int opt_split_vol_pct = 400;  // GRT_OPT_SPLIT_VOL_PCT (rounds 3-5: 50 — "only when the cells' boxes hold under half the proxy's box"; swept in round 6: 50 / 65 / 80 /
+                                  // 100 / 200 / 400 % at sigma 1.0: 3.83 / 3.51 / 3.21 / 2.97 / 2.98 / 2.97 ms; sigma 1.6: 13.8 / . / . / 9.2 / 8.6 / 8.6)
     uint32_t n_hittable = 0;      // particles with opacity > alpha_min (BVH primitives = these, or their pieces)
     bool has_pieces = false;      // the current Gaussian BVH holds pieces of split proxies (the PIECES kernel instantiations)
     float4* d_ovf = nullptr;      // tile kernel: pool of window-overflow bags

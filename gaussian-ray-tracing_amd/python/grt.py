@@ -70,6 +70,7 @@ OPT_OVF_CLASSES = 34
 OPT_BVH_ROTATIONS = 35
 OPT_BUNDLE_PREDICT = 36
 OPT_MESH_PRIMARY_WAVE = 37
+OPT_SPLIT_VOL_PCT = 38
 ERR_LIMIT = -5
 KERNEL_AUTO, KERNEL_PERLANE, KERNEL_WAVE, KERNEL_STREAM, KERNEL_STREAM_BIG, KERNEL_TILE = 0, 1, 2, 3, 4, 5
 

@@ -173,8 +173,9 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
        GRT_OPT_SPLIT = 24             /* spatial splits: a proxy much longer than the typical one whose world box is mostly empty (a needle or
                                          sheet that is not axis-aligned) enters the LBVH as up to 512 pieces, each with the box of its cell;
                                          value = piece length in quarters of the geometric-mean proxy diagonal (8 = 2 x; 0 = off).  Default -1:
-                                         the length follows the scene — 4 when cutting at 8 would add under 15 % of primitives (mildly
-                                         anisotropic proxies, a few times longer than thick: a trained scene), 6 under 50 %, else 8 (scene-sized
+                                         the length follows the scene, by the primitives per proxy that cutting at 8 would give: under 1.02 no
+                                         pieces at all (the benchmark scenes), under 1.25 -> 6 (mildly anisotropic proxies, a few times longer
+                                         than thick: a trained scene), under 1.5 -> 8, under 1.7 -> 10, under 2.2 -> 12, else 16 (scene-sized
                                          needles and sheets, where every piece re-tests its particle).  Pure acceleration structure: same hits,
                                          same pixels.  Per context; next build */,
        GRT_OPT_TILE_BAND_ABS = 25     /* trees with pieces: absolute floor of the tile kernel's leaf band and node look-ahead, in 1/64 of the
@@ -237,7 +238,10 @@ enum { GRT_OPT_COUNTERS = 1 /* 1: use the instrumented kernel and fill grt_count
                                            any lane wants it, one stack per wave), still a kernel of its own; 2 (default): that walk runs
                                            at the head of the tile kernel's primary stage — no launch, no 48-B record per pixel (other
                                            pipelines, and mesh trees too deep for the tile kernel's stack: as 1).  The same hit records bit for
-                                           bit */ };
+                                           bit */,
+       GRT_OPT_SPLIT_VOL_PCT = 38       /* spatial splits: a proxy longer than the piece length is cut when the boxes of its cells together hold
+                                           less than value % of its own box's volume (default 400: practically always; rounds 3-5: 50).  Per context;
+                                           next build.  Same pixels */ };
 
 /* ---- context ---- */
 GRT_API int grt_create(grt_ctx** out, int device);
